@@ -1,0 +1,154 @@
+/* pmg.h -- C ABI of the MI355X-native REINFORCE hot path of paccmann_generator.
+ *
+ * The reference has no FFI: its hot path is a Python loop over a duck-typed decoder
+ * protocol.  Each entry point below replaces one piece of that loop; the citation
+ * names the reference lines (relative to /root/reference/) whose arithmetic it
+ * performs.  Conventions:
+ *   - the caller owns every buffer; all pointers are DEVICE pointers unless noted;
+ *   - the library allocates nothing: scratch comes in through `ws`, sized by
+ *     pmg_workspace_bytes();
+ *   - every call is stream-ordered on the caller's hipStream_t and never synchronises;
+ *   - return value: 0 ok, <0 argument/shape error (pmg_strerror), >0 a hipError_t;
+ *   - weights are in torch layouts (nn.GRU weight_ih_l{k} [3H,in], weight_hh_l{k}
+ *     [3H,H], gate order r,z,n; nn.Linear [out,in]; nn.Embedding [V,E]) so that
+ *     checkpoints load unchanged;
+ *   - fp32 everywhere; token ids are int64 (torch.long), sequence-major [T,B] where
+ *     the reference uses pad_sequence (reinforce_omics.py:304).
+ */
+#ifndef PMG_H
+#define PMG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMG_MAX_LAYERS 4
+#define PMG_ABI_VERSION 1
+
+/* workspace modes */
+#define PMG_MODE_DECODE 0 /* pmg_decode */
+#define PMG_MODE_TRAIN 1  /* pmg_logprob_fwd followed by pmg_reinforce_bwd on the same ws */
+
+/* flags */
+#define PMG_FLAG_NO_EARLY_EXIT 1u /* decode: run all gen_len steps even after every row hit stop */
+#define PMG_FLAG_ACCUMULATE 2u    /* bwd: add into grad_out instead of overwriting it */
+
+typedef void* pmg_stream; /* hipStream_t */
+
+/* Problem shape.  B = sequences in this call, T = time steps:
+ *   decode : T = generate_len (reinforce.py:168)
+ *   train  : T = rows of padded_nums (reinforce_omics.py:304); T-1 decoder steps run.
+ * H rnn_cell_size, E embedding_size, W stack_width, D stack_depth, V vocab_size,
+ * L n_layers, Z decoder latent_dim, pad_idx = nn.Embedding padding_idx (-1: none). */
+typedef struct pmg_shape {
+  int32_t B, T, H, E, W, D, V, L, Z, pad_idx;
+} pmg_shape;
+
+/* Decoder parameters, torch layouts, fp32 device pointers. */
+typedef struct pmg_weights {
+  const float* embedding;            /* [V,E]                                  */
+  const float* w_ih[PMG_MAX_LAYERS]; /* l=0: [3H,E+W]; l>0: [3H,H]             */
+  const float* w_hh[PMG_MAX_LAYERS]; /* [3H,H]                                 */
+  const float* b_ih[PMG_MAX_LAYERS]; /* [3H]                                   */
+  const float* b_hh[PMG_MAX_LAYERS]; /* [3H]                                   */
+  const float* w_ctrl;               /* stack_controls_layer.weight [3,H]      */
+  const float* b_ctrl;               /* [3]                                    */
+  const float* w_push;               /* stack_input_layer.weight [W,H]         */
+  const float* b_push;               /* [W]                                    */
+  const float* w_out;                /* output_layer.weight [V,H]              */
+  const float* b_out;                /* [V]                                    */
+  const float* w_l2h;                /* latent_to_hidden.weight [H,Z] (decode) */
+  const float* b_l2h;                /* [H]                         (decode)   */
+} pmg_weights;
+
+/* Same layout, writable: gradients of the loss w.r.t. each parameter. */
+typedef struct pmg_grads {
+  float* embedding;
+  float* w_ih[PMG_MAX_LAYERS];
+  float* w_hh[PMG_MAX_LAYERS];
+  float* b_ih[PMG_MAX_LAYERS];
+  float* b_hh[PMG_MAX_LAYERS];
+  float* w_ctrl;
+  float* b_ctrl;
+  float* w_push;
+  float* b_push;
+  float* w_out;
+  float* b_out;
+} pmg_grads;
+
+/* ABI version of the loaded library (== PMG_ABI_VERSION). */
+int pmg_abi_version(void);
+
+/* Text for a negative return code. */
+const char* pmg_strerror(int code);
+
+/* 0 if `s` is a shape the kernels support (H in {128,256,512,1024}, W<=64,
+ * 3+W+V<=256, 1<=L<=PMG_MAX_LAYERS, ...); else the error code every entry point
+ * would return for it. */
+int pmg_check_shape(const pmg_shape* s, int mode);
+
+/* Bytes of device scratch needed for `mode` at shape `s` (256-byte aligned base). */
+int pmg_workspace_bytes(const pmg_shape* s, int mode, size_t* out);
+
+/* Batched autoregressive sampling -- replaces generator.generate(...) as called at
+ * reinforce.py:162-170 (TeacherVAE.generate / StackGRUDecoder.generate_from_latent /
+ * SamplingSearch of paccmann_chemistry): h0 = latent_to_hidden(latent) for every
+ * layer, zero stack, feed start_tok, then gen_len x {decoder step, output_layer,
+ * softmax(logits/temperature), one categorical draw}.  temperature <= 0 selects
+ * argmax (GreedySearch).  Draws use Philox4x32-10 keyed by philox_seed with counter
+ * (seq_index_base + row, philox_offset + step), so a batch sharded over GPUs samples
+ * the same tokens as the unsharded batch.
+ *   latent     [B,Z]
+ *   tokens_out [B,gen_len] every sampled token (start token not included)
+ *   len_out    [B] tokens before the first stop_tok (gen_len if none): the crop
+ *              TeacherVAE.generate applies (consumed at reinforce.py:172-187)
+ * A workgroup stops early once all of its rows have emitted stop_tok (remaining
+ * positions are filled with stop_tok) unless PMG_FLAG_NO_EARLY_EXIT is set. */
+int pmg_decode(const pmg_shape* s, const pmg_weights* w, const float* latent,
+               int start_tok, int stop_tok, int gen_len, float temperature,
+               uint64_t philox_seed, uint64_t philox_offset, int64_t seq_index_base,
+               uint32_t flags, int64_t* tokens_out, int32_t* len_out,
+               void* ws, pmg_stream stream);
+
+/* Teacher-forced trajectory log-probs -- replaces the loop at
+ * reinforce_omics.py:319-329 (reinforce_proteins.py:307-318): zero stack, then for
+ * p in 0..T-2: decoder(tokens[p], hidden, stack); output_layer; log_softmax;
+ * gather(tokens[p+1]).  No padding mask (as the reference).  Leaves in `ws` what
+ * pmg_reinforce_bwd needs.
+ *   tokens   [T,B] int64 (pad_sequence layout)
+ *   h0       [L,B,H] = latent_to_hidden(...) (reinforce_omics.py:313-317)
+ *   logp_out [T-1,B]
+ *   h_out    [L,B,H] final hidden, may be NULL */
+int pmg_logprob_fwd(const pmg_shape* s, const pmg_weights* w, const int64_t* tokens,
+                    const float* h0, float* logp_out, float* h_out,
+                    void* ws, pmg_stream stream);
+
+/* Reward-weighted BPTT -- replaces rl_loss.backward() (reinforce_omics.py:335) for
+ * rl_loss = -sum_p mean_b(logp[p,b] * reward[b]) (:330-332), with mean = scale * sum
+ * (scale = 1/B_valid; a data-parallel caller passes 1/B_valid_global).  Must follow
+ * pmg_logprob_fwd with the same shape, tokens, weights and ws.
+ *   reward   [B]
+ *   grad_out gradients of every decoder parameter reachable from the loss
+ *            (latent_to_hidden is reached through grad_h0 by the caller's autograd)
+ *   grad_h0  [L,B,H]
+ *   loss_out [1] */
+int pmg_reinforce_bwd(const pmg_shape* s, const pmg_weights* w, const int64_t* tokens,
+                      const float* reward, float scale, uint32_t flags,
+                      const pmg_grads* grad_out, float* grad_h0, float* loss_out,
+                      void* ws, pmg_stream stream);
+
+/* One decoder step -- the duck-typed `decoder(tok[1,B], hidden, stack)` call of
+ * reinforce_omics.py:323-325 plus `decoder.output_layer` (:326).
+ *   tok [B] int64; hidden_in/out [L,B,H]; stack_in/out [B,D,W]; logits_out [B,V]
+ *   (any of stack_in == NULL means a zero stack; logits_out may be NULL). */
+int pmg_step(const pmg_shape* s, const pmg_weights* w, const int64_t* tok,
+             const float* hidden_in, const float* stack_in, float* hidden_out,
+             float* stack_out, float* logits_out, void* ws, pmg_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMG_H */

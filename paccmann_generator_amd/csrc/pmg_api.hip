@@ -1,0 +1,299 @@
+// Host side of the C ABI (include/pmg.h): shape checks, workspace layout, weight
+// packing and kernel sequencing.  Allocates nothing, never synchronises.
+#include "pmg_kernels.h"
+#include <string.h>
+
+// implemented in pmg_wgrad.hip
+struct WgradArgs;
+hipError_t pmg_run_wgrad(const PmgDims& d, const PmgLayout& lay, float* ws, const pmg_weights* w,
+                         const int64_t* tokens, uint32_t flags, const pmg_grads* grads, float* loss_out,
+                         hipStream_t st);
+size_t pmg_wgrad_acc_floats(const PmgDims& d);
+size_t pmg_wgrad_partial_floats(const PmgDims& d);
+
+static size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
+
+static void make_layout(const PmgDims& d, int mode, PmgLayout* L) {
+  memset(L, 0, sizeof(*L));
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off = align64(off + n); return o; };
+  const size_t H = d.H, G = d.G, T = d.T;
+  L->WXp = take((size_t)d.NXT * 16 * H);
+  L->BX = take((size_t)d.NXT * 16);
+  L->GTAB = take((size_t)d.V * 3 * H);
+  for (int l = 0; l < d.L; ++l) {
+    L->WHHp[l] = take(3 * H * H);
+    L->WIHp[l] = take(l == 0 ? 3 * H * PMG_KS : 3 * H * H);
+    L->BG[l] = take(4 * H);
+  }
+  if (mode == PMG_MODE_DECODE) {
+    L->H0 = take((size_t)H * d.Z);  // packed latent_to_hidden
+    L->SB = take(2 * G * (size_t)d.SW);
+  } else {
+    L->WXt = take((size_t)d.NXT * 16 * H);
+    for (int l = 0; l < d.L; ++l) {
+      L->WHHt[l] = take(3 * H * H);
+      L->WIHt[l] = take(l == 0 ? (size_t)PMG_KS * 3 * H : 3 * H * H);
+    }
+    L->SB = take(T * G * (size_t)d.SW);
+    for (int l = 0; l < d.L; ++l) {
+      L->HH[l] = take(T * G * H * 16);
+      L->GT[l] = take((T - 1) * G * 4 * H * 16);
+      L->DG[l] = take((T - 1) * G * 4 * H * 16);
+    }
+    L->CT = take((T - 1) * G * 64);
+    L->PV = take((T - 1) * G * 1024);
+    L->TP = take((T - 1) * G * 1024);
+    L->PR = take((T - 1) * G * (size_t)d.VP * 16);
+    L->DX = take(T * G * (size_t)d.NXT * 16 * 16);
+    L->DS = take(2 * G * (size_t)d.SW);
+    L->LOSSP = take(G);
+    L->LP = take((T - 1) * G * 16);
+    L->DHC = take(G * (size_t)d.L * H * 16);
+    L->WG = take(pmg_wgrad_acc_floats(d));
+    L->WGP = take(pmg_wgrad_partial_floats(d));
+  }
+  L->total = off;
+}
+
+extern "C" int pmg_abi_version(void) { return PMG_ABI_VERSION; }
+
+extern "C" const char* pmg_strerror(int code) {
+  switch (code) {
+    case PMG_OK: return "ok";
+    case PMG_E_NULL: return "null pointer argument";
+    case PMG_E_SHAPE: return "bad shape: need B>=1, T>=1 (train: T>=2), E>=1, D>=2, Z%32==0";
+    case PMG_E_HIDDEN: return "unsupported rnn_cell_size: H must be 128, 256, 512 or 1024";
+    case PMG_E_STACK: return "unsupported stack: need 1<=W<=64, 2<=D";
+    case PMG_E_VOCAB: return "unsupported vocabulary: need 3+W+V<=256";
+    case PMG_E_LAYERS: return "unsupported n_layers: need 1<=L<=4";
+    case PMG_E_ALIGN: return "pointer not 16-byte aligned";
+    case PMG_E_MODE: return "unknown workspace mode";
+    case PMG_E_ARG: return "bad argument";
+    case PMG_E_LDS: return "shape needs more than 160 KiB of LDS per workgroup";
+  }
+  return code > 0 ? "HIP runtime error (see hipGetErrorString)" : "unknown error";
+}
+
+extern "C" int pmg_check_shape(const pmg_shape* s, int mode) {
+  if (!s) return PMG_E_NULL;
+  if (mode != PMG_MODE_DECODE && mode != PMG_MODE_TRAIN) return PMG_E_MODE;
+  if (s->H != 128 && s->H != 256 && s->H != 512 && s->H != 1024) return PMG_E_HIDDEN;
+  if (s->L < 1 || s->L > PMG_MAX_LAYERS) return PMG_E_LAYERS;
+  if (s->W < 1 || s->W > PMG_KS || s->D < 2) return PMG_E_STACK;
+  if (s->V < 2 || 3 + s->W + s->V > 256) return PMG_E_VOCAB;
+  if (s->B < 1 || s->T < 1 || s->E < 1) return PMG_E_SHAPE;
+  if (mode == PMG_MODE_TRAIN && s->T < 2) return PMG_E_SHAPE;
+  if (mode == PMG_MODE_DECODE && (s->Z < 32 || s->Z % 32 != 0)) return PMG_E_SHAPE;
+  const PmgDims d = pmg_dims(s);
+  size_t lds = ((size_t)d.L * 16 * d.HP + 16 * PMG_XTP + (size_t)16 * d.XP + 32) * 4;
+  if (mode == PMG_MODE_DECODE) lds += (size_t)16 * (d.Z + 8) * 4;
+  if (lds > 160 * 1024) return PMG_E_LDS;
+  return PMG_OK;
+}
+
+extern "C" int pmg_workspace_bytes(const pmg_shape* s, int mode, size_t* out) {
+  if (!out) return PMG_E_NULL;
+  const int rc = pmg_check_shape(s, mode);
+  if (rc) return rc;
+  PmgLayout lay;
+  make_layout(pmg_dims(s), mode, &lay);
+  *out = lay.total * sizeof(float) + 256;
+  return PMG_OK;
+}
+
+static float* ws_base(void* ws) {
+  return reinterpret_cast<float*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+}
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+// Pack the forward operands (and, for training, the transposed ones).
+static int pack_weights(const PmgDims& d, const PmgLayout& lay, float* base, const pmg_weights* w, int mode,
+                        bool with_l2h, hipStream_t st) {
+  PackArgs p;
+  memset(&p, 0, sizeof(p));
+  p.H = d.H; p.E = d.E; p.W = d.W; p.V = d.V; p.NX = d.NX; p.UPW = d.UPW; p.Z = d.Z;
+  // extras
+  p.kind = PK_WX; p.tiles = d.NXT; p.KG = d.KGH; p.src = w->w_ctrl; p.src2 = w->w_push; p.src3 = w->w_out;
+  p.dst = base + lay.WXp;
+  HIPCHK(pmg_launch_pack(&p, st));
+  for (int l = 0; l < d.L; ++l) {
+    p.kind = PK_WHH; p.tiles = 3 * d.UT; p.KG = d.KGH; p.src = w->w_hh[l]; p.dst = base + lay.WHHp[l];
+    HIPCHK(pmg_launch_pack(&p, st));
+    if (l == 0) { p.kind = PK_WIS; p.KG = PMG_KS / 16; } else { p.kind = PK_WIH; p.KG = d.KGH; }
+    p.src = w->w_ih[l]; p.dst = base + lay.WIHp[l];
+    HIPCHK(pmg_launch_pack(&p, st));
+  }
+  if (mode == PMG_MODE_DECODE) {
+    if (with_l2h) {
+    p.kind = PK_L2H; p.tiles = d.UT; p.KG = d.Z / 16; p.src = w->w_l2h; p.dst = base + lay.H0;
+    HIPCHK(pmg_launch_pack(&p, st));
+    }
+  } else {
+    p.kind = PK_WXT; p.tiles = d.UT; p.KG = d.NXT; p.src = w->w_ctrl; p.src2 = w->w_push; p.src3 = w->w_out;
+    p.dst = base + lay.WXt;
+    HIPCHK(pmg_launch_pack(&p, st));
+    for (int l = 0; l < d.L; ++l) {
+      p.kind = PK_WHHT; p.tiles = d.UT; p.KG = 3 * d.H / 16; p.src = w->w_hh[l]; p.dst = base + lay.WHHt[l];
+      HIPCHK(pmg_launch_pack(&p, st));
+      if (l == 0) { p.kind = PK_WIST; p.tiles = PMG_KS / 16; } else { p.kind = PK_WIHT; p.tiles = d.UT; }
+      p.src = w->w_ih[l]; p.dst = base + lay.WIHt[l];
+      HIPCHK(pmg_launch_pack(&p, st));
+    }
+  }
+  AuxArgs x;
+  memset(&x, 0, sizeof(x));
+  x.H = d.H; x.E = d.E; x.W = d.W; x.V = d.V; x.L = d.L; x.NX = d.NX; x.NXT = d.NXT;
+  x.b_ctrl = w->b_ctrl; x.b_push = w->b_push; x.b_out = w->b_out;
+  for (int l = 0; l < d.L; ++l) { x.b_ih[l] = w->b_ih[l]; x.b_hh[l] = w->b_hh[l]; x.BG[l] = base + lay.BG[l]; }
+  x.emb = w->embedding; x.w_ih0 = w->w_ih[0];
+  x.BX = base + lay.BX; x.GTAB = base + lay.GTAB;
+  HIPCHK(pmg_launch_aux(&x, st));
+  return PMG_OK;
+}
+
+static int check_weights(const pmg_shape* s, const pmg_weights* w, bool need_l2h) {
+  if (!w || !w->embedding || !w->w_ctrl || !w->b_ctrl || !w->w_push || !w->b_push || !w->w_out || !w->b_out)
+    return PMG_E_NULL;
+  for (int l = 0; l < s->L; ++l)
+    if (!w->w_ih[l] || !w->w_hh[l] || !w->b_ih[l] || !w->b_hh[l]) return PMG_E_NULL;
+  if (need_l2h && (!w->w_l2h || !w->b_l2h)) return PMG_E_NULL;
+  return PMG_OK;
+}
+
+static void fill_fwd_common(FwdArgs* a, const PmgDims& d, const PmgLayout& lay, float* base) {
+  memset(a, 0, sizeof(*a));
+  a->B = d.B; a->G = d.G; a->H = d.H; a->W = d.W; a->D = d.D; a->V = d.V; a->L = d.L; a->Z = d.Z;
+  a->NX = d.NX; a->NXT = d.NXT; a->XP = d.XP; a->HP = d.HP; a->KGH = d.KGH; a->VP = d.VP; a->SW = d.SW;
+  a->WXp = reinterpret_cast<const float4*>(base + lay.WXp);
+  a->BX = base + lay.BX;
+  a->GTAB = base + lay.GTAB;
+  for (int l = 0; l < d.L; ++l) {
+    a->WHHp[l] = reinterpret_cast<const float4*>(base + lay.WHHp[l]);
+    a->WIHp[l] = reinterpret_cast<const float4*>(base + lay.WIHp[l]);
+    a->BG[l] = base + lay.BG[l];
+  }
+  a->SB = base + lay.SB;
+}
+
+extern "C" int pmg_decode(const pmg_shape* s, const pmg_weights* w, const float* latent, int start_tok,
+                          int stop_tok, int gen_len, float temperature, uint64_t philox_seed,
+                          uint64_t philox_offset, int64_t seq_index_base, uint32_t flags, int64_t* tokens_out,
+                          int32_t* len_out, void* ws, pmg_stream stream) {
+  int rc = pmg_check_shape(s, PMG_MODE_DECODE);
+  if (rc) return rc;
+  if (!latent || !tokens_out || !len_out || !ws) return PMG_E_NULL;
+  if ((rc = check_weights(s, w, true))) return rc;
+  if (gen_len < 1 || gen_len != s->T) return PMG_E_ARG;
+  if (start_tok < 0 || start_tok >= s->V) return PMG_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const PmgDims d = pmg_dims(s);
+  PmgLayout lay;
+  make_layout(d, PMG_MODE_DECODE, &lay);
+  float* base = ws_base(ws);
+  if ((rc = pack_weights(d, lay, base, w, PMG_MODE_DECODE, true, st))) return rc;
+  FwdArgs a;
+  fill_fwd_common(&a, d, lay, base);
+  a.mode = PMG_FWD_DECODE;
+  a.N = gen_len;
+  a.start_tok = start_tok; a.stop_tok = stop_tok; a.temperature = temperature; a.flags = flags;
+  a.seed = philox_seed; a.offset = philox_offset; a.seq_base = seq_index_base;
+  a.L2Hp = reinterpret_cast<const float4*>(base + lay.H0);
+  a.b_l2h = w->b_l2h;
+  a.latent = latent;
+  a.tok_out = tokens_out; a.len_out = len_out;
+  HIPCHK(pmg_launch_fwd(&a, st));
+  return PMG_OK;
+}
+
+static void fill_history(FwdArgs* a, const PmgDims& d, const PmgLayout& lay, float* base) {
+  for (int l = 0; l < d.L; ++l) { a->HH[l] = base + lay.HH[l]; a->GT[l] = base + lay.GT[l]; }
+  a->CT = base + lay.CT; a->PV = base + lay.PV; a->TP = base + lay.TP; a->PR = base + lay.PR;
+  a->LP = base + lay.LP;
+}
+
+extern "C" int pmg_logprob_fwd(const pmg_shape* s, const pmg_weights* w, const int64_t* tokens, const float* h0,
+                               float* logp_out, float* h_out, void* ws, pmg_stream stream) {
+  int rc = pmg_check_shape(s, PMG_MODE_TRAIN);
+  if (rc) return rc;
+  if (!tokens || !h0 || !logp_out || !ws) return PMG_E_NULL;
+  if ((rc = check_weights(s, w, false))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const PmgDims d = pmg_dims(s);
+  PmgLayout lay;
+  make_layout(d, PMG_MODE_TRAIN, &lay);
+  float* base = ws_base(ws);
+  if ((rc = pack_weights(d, lay, base, w, PMG_MODE_TRAIN, false, st))) return rc;
+  FwdArgs a;
+  fill_fwd_common(&a, d, lay, base);
+  fill_history(&a, d, lay, base);
+  a.mode = PMG_FWD_TEACHER;
+  a.N = d.T - 1;
+  a.h0 = h0; a.tok_in = tokens; a.logp_out = logp_out; a.h_out = h_out;
+  HIPCHK(pmg_launch_fwd(&a, st));
+  return PMG_OK;
+}
+
+extern "C" int pmg_step(const pmg_shape* s, const pmg_weights* w, const int64_t* tok, const float* hidden_in,
+                        const float* stack_in, float* hidden_out, float* stack_out, float* logits_out, void* ws,
+                        pmg_stream stream) {
+  pmg_shape s1 = *s;
+  s1.T = 1;
+  if (s1.Z < 32 || s1.Z % 32) s1.Z = 32;  // latent_to_hidden is not used by a step
+  int rc = pmg_check_shape(&s1, PMG_MODE_DECODE);
+  if (rc) return rc;
+  if (!tok || !hidden_in || !hidden_out || !ws) return PMG_E_NULL;
+  if ((rc = check_weights(&s1, w, false))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const PmgDims d = pmg_dims(&s1);
+  PmgLayout lay;
+  make_layout(d, PMG_MODE_DECODE, &lay);
+  float* base = ws_base(ws);
+  if ((rc = pack_weights(d, lay, base, w, PMG_MODE_DECODE, false, st))) return rc;
+  FwdArgs a;
+  fill_fwd_common(&a, d, lay, base);
+  a.mode = PMG_FWD_STEP;
+  a.N = 1;
+  a.h0 = hidden_in; a.tok_in = tok; a.stack_in = stack_in;
+  a.h_out = hidden_out; a.stack_out = stack_out; a.logits_out = logits_out;
+  HIPCHK(pmg_launch_fwd(&a, st));
+  return PMG_OK;
+}
+
+extern "C" int pmg_reinforce_bwd(const pmg_shape* s, const pmg_weights* w, const int64_t* tokens,
+                                 const float* reward, float scale, uint32_t flags, const pmg_grads* grad_out,
+                                 float* grad_h0, float* loss_out, void* ws, pmg_stream stream) {
+  int rc = pmg_check_shape(s, PMG_MODE_TRAIN);
+  if (rc) return rc;
+  if (!tokens || !reward || !grad_out || !grad_h0 || !loss_out || !ws) return PMG_E_NULL;
+  if ((rc = check_weights(s, w, false))) return rc;
+  if (!grad_out->embedding || !grad_out->w_ctrl || !grad_out->b_ctrl || !grad_out->w_push || !grad_out->b_push ||
+      !grad_out->w_out || !grad_out->b_out)
+    return PMG_E_NULL;
+  for (int l = 0; l < s->L; ++l)
+    if (!grad_out->w_ih[l] || !grad_out->w_hh[l] || !grad_out->b_ih[l] || !grad_out->b_hh[l]) return PMG_E_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  const PmgDims d = pmg_dims(s);
+  PmgLayout lay;
+  make_layout(d, PMG_MODE_TRAIN, &lay);
+  float* base = ws_base(ws);
+  BwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = d.B; a.G = d.G; a.N = d.T - 1; a.H = d.H; a.W = d.W; a.D = d.D; a.V = d.V; a.L = d.L;
+  a.NX = d.NX; a.NXT = d.NXT; a.XP = d.XP; a.KGH = d.KGH; a.VP = d.VP; a.SW = d.SW; a.UPW = d.UPW;
+  a.scale = scale; a.tokens = tokens; a.reward = reward;
+  a.WXt = reinterpret_cast<const float4*>(base + lay.WXt);
+  for (int l = 0; l < d.L; ++l) {
+    a.WHHt[l] = reinterpret_cast<const float4*>(base + lay.WHHt[l]);
+    a.WIHt[l] = reinterpret_cast<const float4*>(base + lay.WIHt[l]);
+    a.HH[l] = base + lay.HH[l]; a.GT[l] = base + lay.GT[l]; a.DG[l] = base + lay.DG[l];
+  }
+  a.SB = base + lay.SB; a.CT = base + lay.CT; a.PV = base + lay.PV; a.PR = base + lay.PR;
+  a.LP = base + lay.LP;
+  a.DX = base + lay.DX; a.DS = base + lay.DS; a.DHC = base + lay.DHC; a.grad_h0 = grad_h0;
+  a.LOSSP = base + lay.LOSSP;
+  HIPCHK(pmg_launch_bwd(&a, st));
+  HIPCHK(pmg_run_wgrad(d, lay, base, w, tokens, flags, grad_out, loss_out, st));
+  return PMG_OK;
+}

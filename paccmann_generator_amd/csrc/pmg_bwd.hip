@@ -1,0 +1,356 @@
+// Persistent reward-weighted BPTT through the StackGRU (the recurrent half of
+// rl_loss.backward(), reference: reinforce_omics.py:335).  Weight gradients are NOT
+// formed here: this kernel walks time backwards, produces the per-step gate / extras
+// gradients (DG, DX row slabs) and grad_h0; pmg_wgrad.hip contracts those slabs with
+// the saved activations in one large-K GEMM.
+//
+// Same decomposition as the forward: one workgroup = 16 sequences, 8 waves, D layout.
+// Per reverse step p and layer l (top first):
+//   dh      = carry[l] (+ W_ih^{l+1,T} dgi^{l+1} from the layer above, this step)
+//   dgates  = GRU cell backward (r,z,n,ghn,h_prev saved by the forward)
+//   carry'[l] = z*dh + W_hh^T dgh          (MFMA, transposed packed weights)
+//   dx        = W_ih^T dgi                 (layer 0: only the stack-top columns)
+// then the stack backward (blend, softmax, tanh) and
+//   carry'[L-1] += [W_ctrl; W_push; W_out]^T [dctrl_p | dpush_p | dlogits_{p-1}].
+// The algorithm is restated line by line in oracle/fused_model.py (forward_backward).
+#include "pmg_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  f32x4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r;
+}
+__device__ __forceinline__ void st4(float* p, const f32x4 v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v.x, v.y, v.z, v.w);
+}
+
+// acc[t] += Wt[tile t][groups of this chunk] * chunk columns.  24 reduction groups:
+// 8 per piece; pcN = LDS column block (of 128) holding piece N of this product.
+template <int NT>
+__device__ __forceinline__ void gemm_chunk(f32x4 (&acc)[NT], const float4* __restrict__ wp, const size_t ts,
+                                           const float* xb, const int pc0, const int pc1, const int pc2) {
+  float4 wc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wc[t] = wp[t * ts];
+#pragma unroll 1
+  for (int rg = 0; rg < 24; ++rg) {
+    const int piece = rg >> 3;
+    const int pc = (piece == 0) ? pc0 : (piece == 1) ? pc1 : pc2;
+    const float4 x = *reinterpret_cast<const float4*>(xb + pc * PMG_CHUNK + (rg & 7) * 16);
+    const int rn = (rg + 1 < 24) ? rg + 1 : rg;
+    float4 wn[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wn[t] = wp[t * ts + (size_t)rn * 64];
+#define PMG_STEP(C)                                                                      \
+  _Pragma("unroll") for (int t = 0; t < NT; ++t)                                         \
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[t].C, x.C, acc[t], 0, 0, 0);
+    PMG_STEP(x) PMG_STEP(y) PMG_STEP(z) PMG_STEP(w)
+#undef PMG_STEP
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wc[t] = wn[t];
+  }
+}
+
+// acc[t] += Wt[tile t][0..KG) * x[b][0..16*KG)   (plain contiguous reduction)
+template <int NT>
+__device__ __forceinline__ void gemm_lin(f32x4 (&acc)[NT], const float4* __restrict__ wp, const size_t ts,
+                                         const float* xrow, const int KG) {
+#pragma unroll 1
+  for (int kg = 0; kg < KG; ++kg) {
+    const float4 x = *reinterpret_cast<const float4*>(xrow + 16 * kg);
+    float4 wc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wc[t] = wp[t * ts + (size_t)kg * 64];
+#define PMG_STEP(C)                                                                      \
+  _Pragma("unroll") for (int t = 0; t < NT; ++t)                                         \
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[t].C, x.C, acc[t], 0, 0, 0);
+    PMG_STEP(x) PMG_STEP(y) PMG_STEP(z) PMG_STEP(w)
+#undef PMG_STEP
+  }
+}
+
+template <int UPW>
+__global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int H = a.H, XP = a.XP, W = a.W, D = a.D, V = a.V, L = a.L, B = a.B, G = a.G, N = a.N;
+  const int UT = H / 16, NXT = a.NXT;
+  float* cb = reinterpret_cast<float*>(smem);   // [2][16][PMG_CP]
+  float* dxl = cb + 2 * 16 * PMG_CP;            // [16][XP]   dctrl | dpush | dlogits
+  float* dtl = dxl + 16 * XP;                   // [16][PMG_XTP] dtop
+  float* red = dtl + 16 * PMG_XTP;              // [8][4][12]
+  float* lsl = red + PMG_WAVES * 48;            // [16] loss terms
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int b = lane & 15, q = lane >> 4;
+  const int g = blockIdx.x;
+  const int row0 = g * PMG_ROWS;
+  const size_t KG3 = (size_t)3 * H / 16;  // reduction groups of the gate products
+
+  float* dhc = a.DHC + (size_t)g * L * H * 16;
+  // zero the carry (own elements only: each lane re-reads exactly what it wrote)
+  for (int l = 0; l < L; ++l)
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) {
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      st4(dhc + ((size_t)(l * UT + wave * UPW + u)) * 256 + lane * 4, z4);
+    }
+  for (int idx = tid; idx < 16 * XP; idx += PMG_THREADS) dxl[idx] = 0.0f;
+  for (int idx = tid; idx < 16 * PMG_XTP; idx += PMG_THREADS) dtl[idx] = 0.0f;
+  float lossacc = 0.0f;  // threads 0..15: sum_p R_b * logp[p][b]
+  float myR = 0.0f;
+  if (tid < 16) myR = (row0 + tid < B) ? a.reward[row0 + tid] : 0.0f;
+  __syncthreads();
+
+  int par = 0;  // chunk buffer parity, alternates on every chunk
+
+  // p == N is the virtual step that only injects dlogits_{N-1}
+  for (int p = N; p >= 0; --p) {
+    const bool virt = (p == N);
+    if (!virt) {
+      f32x4 dxa[UPW];
+#pragma unroll
+      for (int u = 0; u < UPW; ++u) dxa[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int l = L - 1; l >= 0; --l) {
+        f32x4 dh[UPW], acc_hh[UPW], acc_dx[UPW];
+        f32x4 acc_top[1];
+        acc_top[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < UPW; ++u) {
+          dh[u] = ld4(dhc + ((size_t)(l * UT + wave * UPW + u)) * 256 + lane * 4);
+          if (l < L - 1) dh[u] += dxa[u];
+          acc_hh[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          acc_dx[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const float* gt_base = a.GT[l] + (((size_t)p * G + g) * UT) * 1024;
+        const float* hh_base = a.HH[l] + (((size_t)p * G + g) * H) * 16;
+        float* dg_base = a.DG[l] + (((size_t)p * G + g) * 4 * H) * 16;
+#pragma unroll
+        for (int c = 0; c < UPW; ++c) {
+          // ---- GRU cell backward for unit tile c of this wave
+          const int ug = wave * UPW + c;
+          const int j0 = 16 * ug + 4 * q;
+          const float* gp = gt_base + (size_t)ug * 1024 + lane * 4;
+          const f32x4 r = ld4(gp), z = ld4(gp + 256), n = ld4(gp + 512), ghn = ld4(gp + 768);
+          f32x4 hp;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) hp[j] = hh_base[(size_t)(j0 + j) * 16 + b];
+          const f32x4 d = dh[c];
+          f32x4 dr_pre, dz_pre, dn_pre, dghn;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float dn = d[j] * (1.0f - z[j]);
+            const float dz = d[j] * (hp[j] - n[j]);
+            dn_pre[j] = dn * (1.0f - n[j] * n[j]);
+            const float dr = dn_pre[j] * ghn[j];
+            dghn[j] = dn_pre[j] * r[j];
+            dz_pre[j] = dz * z[j] * (1.0f - z[j]);
+            dr_pre[j] = dr * r[j] * (1.0f - r[j]);
+          }
+          acc_hh[c] += d * z;
+          float* cbw = cb + (size_t)par * 16 * PMG_CP + b * PMG_CP + 16 * wave + 4 * q;
+          st4(cbw, dr_pre); st4(cbw + PMG_CHUNK, dz_pre); st4(cbw + 2 * PMG_CHUNK, dn_pre);
+          st4(cbw + 3 * PMG_CHUNK, dghn);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            dg_base[((size_t)(0 * H + j0 + j)) * 16 + b] = dr_pre[j];
+            dg_base[((size_t)(1 * H + j0 + j)) * 16 + b] = dz_pre[j];
+            dg_base[((size_t)(2 * H + j0 + j)) * 16 + b] = dn_pre[j];
+            dg_base[((size_t)(3 * H + j0 + j)) * 16 + b] = dghn[j];
+          }
+          __syncthreads();
+          // ---- products over this chunk's 3*128 reduction rows
+          const float* xb = cb + (size_t)par * 16 * PMG_CP + b * PMG_CP + 4 * q;
+          {
+            const float4* wp = a.WHHt[l] + ((size_t)(wave * UPW) * KG3 + (size_t)c * 24) * 64 + lane;
+            gemm_chunk<UPW>(acc_hh, wp, KG3 * 64, xb, 0, 1, 3);
+          }
+          if (l > 0) {
+            const float4* wp = a.WIHt[l] + ((size_t)(wave * UPW) * KG3 + (size_t)c * 24) * 64 + lane;
+            gemm_chunk<UPW>(acc_dx, wp, KG3 * 64, xb, 0, 1, 2);
+          } else if (wave < PMG_KS / 16) {
+            const float4* wp = a.WIHt[0] + ((size_t)wave * KG3 + (size_t)c * 24) * 64 + lane;
+            gemm_chunk<1>(acc_top, wp, KG3 * 64, xb, 0, 1, 2);
+          }
+          par ^= 1;
+        }
+#pragma unroll
+        for (int u = 0; u < UPW; ++u) {
+          st4(dhc + ((size_t)(l * UT + wave * UPW + u)) * 256 + lane * 4, acc_hh[u]);
+          dxa[u] = acc_dx[u];
+        }
+        if (l == 0 && wave < PMG_KS / 16) st4(dtl + b * PMG_XTP + 16 * wave + 4 * q, acc_top[0]);
+      }
+      __syncthreads();  // dtop visible; chunk buffers free
+    }
+
+    // ------------------------------------------------------------ stack backward
+    if (!virt) {
+      const int ncol = W * 4;
+      int dsplit = PMG_THREADS / ncol;
+      if (dsplit < 1) dsplit = 1;
+      if (dsplit > D) dsplit = D;
+      const int dch = (D + dsplit - 1) / dsplit;
+      const float* Sprev = a.SB + ((size_t)p * G + g) * a.SW;
+      const float* dSin = a.DS + ((size_t)((p + 1) & 1) * G + g) * a.SW;
+      float* dSout = a.DS + ((size_t)(p & 1) * G + g) * a.SW;
+      const bool zero_S = (p == 0);
+      const bool zero_dS = (p == N - 1);
+      const float* ct = a.CT + ((size_t)p * G + g) * 64;
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      f32x4 sn = zero4, sp = zero4, sq = zero4;
+      for (int item = tid; item < ncol * dsplit; item += PMG_THREADS) {
+        const int bq = item & 3;
+        const int cw = item >> 2;
+        const int w = cw % W;
+        const int part = cw / W;
+        const int d0 = part * dch;
+        const int d1 = (d0 + dch < D) ? d0 + dch : D;
+        if (d0 >= d1) continue;
+        const f32x4 apush = ld4(ct + 0 * 16 + 4 * bq), apop = ld4(ct + 1 * 16 + 4 * bq),
+                    anoop = ld4(ct + 2 * 16 + 4 * bq);
+        const f32x4 pv = ld4(a.PV + ((size_t)p * G + g) * 1024 + w * 16 + 4 * bq);
+        f32x4 dtop4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dtop4[j] = dtl[(4 * bq + j) * PMG_XTP + w];
+        const size_t cofs = (size_t)w * 16 + 4 * bq;
+#define LD_S(dd) (((dd) < 0 || (dd) >= D || zero_S) ? zero4 : ld4(Sprev + (size_t)(dd) * W * 16 + cofs))
+#define LD_G(dd)                                                                              \
+  (((dd) < 0 || (dd) >= D) ? zero4                                                            \
+                           : ((zero_dS ? zero4 : ld4(dSin + (size_t)(dd) * W * 16 + cofs)) + \
+                              (((dd) == 0) ? dtop4 : zero4)))
+        f32x4 gm = LD_G(d0 - 1), gc = LD_G(d0);
+        f32x4 sm = (d0 == 0) ? pv : LD_S(d0 - 1);
+        f32x4 sc = LD_S(d0);
+        for (int d = d0; d < d1; ++d) {
+          const f32x4 gn = LD_G(d + 1);
+          const f32x4 sx = LD_S(d + 1);
+          sn += gc * sc;
+          sp += gc * sm;
+          sq += gc * sx;
+          const f32x4 dprev = anoop * gc + apush * gn + apop * gm;
+          st4(dSout + (size_t)d * W * 16 + cofs, dprev);
+          if (d == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float dv = apush[j] * gc[j];
+              dxl[(4 * bq + j) * XP + 3 + w] = dv * (1.0f - pv[j] * pv[j]);
+            }
+          }
+          gm = gc; gc = gn; sm = sc; sc = sx;
+        }
+#undef LD_S
+#undef LD_G
+      }
+      // reduce the control-gradient partials over the lanes that share bq = lane&3
+#pragma unroll
+      for (int o = 4; o < 64; o <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sn[j] += __shfl_xor(sn[j], o);
+          sp[j] += __shfl_xor(sp[j], o);
+          sq[j] += __shfl_xor(sq[j], o);
+        }
+      }
+      if (lane < 4) {
+        float* rp = red + (wave * 4 + lane) * 12;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { rp[j] = sp[j]; rp[4 + j] = sq[j]; rp[8 + j] = sn[j]; }
+      }
+    }
+    // ------------------------------------------------------------ dlogits_{p-1}, loss
+    {
+      const float sc = a.scale;
+      for (int idx = tid; idx < 16 * V; idx += PMG_THREADS) {
+        const int bb = idx & 15, v = idx >> 4;
+        float val = 0.0f;
+        if (p >= 1) {
+          const int row = row0 + bb;
+          const float R = (row < B) ? a.reward[row] : 0.0f;
+          const int y = (row < B) ? (int)a.tokens[(size_t)p * B + row] : 0;
+          const float pr = a.PR[(((size_t)(p - 1) * G + g) * a.VP + v) * 16 + bb];
+          val = sc * R * (pr - ((v == y) ? 1.0f : 0.0f));
+        }
+        dxl[bb * XP + 3 + W + v] = val;
+      }
+      if (p >= 1 && tid < 16) lossacc += myR * a.LP[((size_t)(p - 1) * G + g) * 16 + tid];
+    }
+    __syncthreads();
+    if (!virt && tid < 16) {
+      const int bq = tid >> 2, j = tid & 3;
+      float dpu = 0.f, dpo = 0.f, dno = 0.f;
+      for (int wv = 0; wv < PMG_WAVES; ++wv) {
+        const float* rp = red + (wv * 4 + bq) * 12;
+        dpu += rp[j]; dpo += rp[4 + j]; dno += rp[8 + j];
+      }
+      const float* ct = a.CT + ((size_t)p * G + g) * 64;
+      const float a0 = ct[tid], a1 = ct[16 + tid], a2 = ct[32 + tid];
+      const float s = a0 * dpu + a1 * dpo + a2 * dno;
+      dxl[tid * XP + 0] = a0 * (dpu - s);
+      dxl[tid * XP + 1] = a1 * (dpo - s);
+      dxl[tid * XP + 2] = a2 * (dno - s);
+    }
+    __syncthreads();
+    // ------------------------------------------------------------ DX slab + extras product
+    {
+      float* dxg = a.DX + ((size_t)p * G + g) * NXT * 256;
+      for (int idx = tid; idx < NXT * 256; idx += PMG_THREADS) {
+        const int bb = idx & 15, nrow = idx >> 4;
+        dxg[idx] = dxl[bb * XP + nrow];
+      }
+      f32x4 acc[UPW];
+#pragma unroll
+      for (int u = 0; u < UPW; ++u) acc[u] = ld4(dhc + ((size_t)((L - 1) * UT + wave * UPW + u)) * 256 + lane * 4);
+      const float4* wp = a.WXt + ((size_t)(wave * UPW) * NXT) * 64 + lane;
+      gemm_lin<UPW>(acc, wp, (size_t)NXT * 64, dxl + b * XP + 4 * q, NXT);
+#pragma unroll
+      for (int u = 0; u < UPW; ++u) st4(dhc + ((size_t)((L - 1) * UT + wave * UPW + u)) * 256 + lane * 4, acc[u]);
+    }
+    __syncthreads();  // dxl / dtl / red reusable
+  }
+
+  // ---------------------------------------------------------------- outputs
+  for (int l = 0; l < L; ++l)
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) {
+      const f32x4 v = ld4(dhc + ((size_t)(l * UT + wave * UPW + u)) * 256 + lane * 4);
+      const int row = row0 + b;
+      if (row < B) st4(a.grad_h0 + ((size_t)l * B + row) * H + 16 * (wave * UPW + u) + 4 * q, v);
+    }
+  if (tid < 16) lsl[tid] = lossacc;
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.0f;
+    for (int i = 0; i < 16; ++i) s += lsl[i];
+    a.LOSSP[g] = -a.scale * s;
+  }
+}
+
+}  // namespace
+
+size_t pmg_bwd_lds_bytes(const BwdArgs* a) {
+  return ((size_t)2 * 16 * PMG_CP + (size_t)16 * a->XP + 16 * PMG_XTP + PMG_WAVES * 48 + 16) * sizeof(float);
+}
+
+template <int UPW>
+static hipError_t launch_bwd_t(const BwdArgs* a, hipStream_t st) {
+  const size_t lds = pmg_bwd_lds_bytes(a);
+  auto kern = pmg_bwd_kernel<UPW>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(a->G), dim3(PMG_THREADS), lds, st, *a);
+  return hipGetLastError();
+}
+
+hipError_t pmg_launch_bwd(const BwdArgs* a, hipStream_t st) {
+  switch (a->H) {
+    case 128: return launch_bwd_t<1>(a, st);
+    case 256: return launch_bwd_t<2>(a, st);
+    case 512: return launch_bwd_t<4>(a, st);
+    case 1024: return launch_bwd_t<8>(a, st);
+  }
+  return hipErrorInvalidValue;
+}

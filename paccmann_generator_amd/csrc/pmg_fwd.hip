@@ -1,0 +1,472 @@
+// Persistent fused StackGRU forward: sampling decode, teacher-forced log-probs and the
+// single-step form, one kernel.
+//
+// One workgroup owns 16 sequences for every time step.  Hidden state lives in LDS, the
+// differentiable stack in a private row-slab of the workspace (L2/Infinity-Cache
+// resident; in teacher-forced mode the slab of every step is kept because the backward
+// needs it), weights stream from L2 in the packed layout of pmg_pack.hip.
+//
+// Arithmetic per step (reference call sites: reinforce_omics.py:323-329,
+// reinforce.py:162-170; decoder restated in oracle/stack_gru.py):
+//   extras = [W_ctrl; W_push; W_out] h_{i-1}^{top} + b      (one GEMM, K = H)
+//      -> logits of step i-1 (sample / log-softmax), stack controls and push value of step i
+//   stack update (push/pop/no-op blend), top row -> GRU input
+//   per layer: gates = W_hh h_old (+ W_ih x), layer 0 adds the per-token table GTAB[tok]
+//   h_new = (h_old - n) * z + n
+#include "pmg_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  f32x4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r;
+}
+__device__ __forceinline__ void st4(float* p, const f32x4 v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v.x, v.y, v.z, v.w);
+}
+
+// acc{r,z,t}[u0..u0+TPP) += W[tiles 3*u0 ..] * X   over KG groups of 16 columns.
+// wp points at (first tile, kg 0, this lane); xrow at this lane's LDS row + 4*(lane>>4).
+template <int UPW, int TPP>
+__device__ __forceinline__ void gemm3_pass(f32x4 (&ar)[UPW], f32x4 (&az)[UPW], f32x4 (&at)[UPW], const int u0,
+                                           const float4* __restrict__ wp, const int KG, const float* xrow) {
+  constexpr int NT = 3 * TPP;
+  const size_t ts = (size_t)KG * 64;
+  float4 wc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wc[t] = wp[t * ts];
+#pragma unroll 1
+  for (int kg = 0; kg < KG; ++kg) {
+    const float4 x = *reinterpret_cast<const float4*>(xrow + 16 * kg);
+    const int kn = (kg + 1 < KG) ? kg + 1 : kg;
+    float4 wn[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wn[t] = wp[t * ts + (size_t)kn * 64];
+#define PMG_STEP(C)                                                                              \
+  _Pragma("unroll") for (int uu = 0; uu < TPP; ++uu) {                                           \
+    ar[u0 + uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[3 * uu + 0].C, x.C, ar[u0 + uu], 0, 0, 0); \
+    az[u0 + uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[3 * uu + 1].C, x.C, az[u0 + uu], 0, 0, 0); \
+    at[u0 + uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[3 * uu + 2].C, x.C, at[u0 + uu], 0, 0, 0); \
+  }
+    PMG_STEP(x) PMG_STEP(y) PMG_STEP(z) PMG_STEP(w)
+#undef PMG_STEP
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wc[t] = wn[t];
+  }
+}
+
+template <int UPW, int TPP>
+__device__ __forceinline__ void gemm3(f32x4 (&ar)[UPW], f32x4 (&az)[UPW], f32x4 (&at)[UPW],
+                                      const float4* __restrict__ wbase, const int KG, const float* xrow,
+                                      const int wave, const int lane) {
+  // this wave's tiles: 3*(wave*UPW + u), u in [0,UPW)
+#pragma unroll
+  for (int ps = 0; ps < UPW / TPP; ++ps) {
+    const int u0 = ps * TPP;
+    const float4* wp = wbase + ((size_t)(3 * (wave * UPW + u0)) * KG) * 64 + lane;
+    gemm3_pass<UPW, TPP>(ar, az, at, u0, wp, KG, xrow);
+  }
+}
+
+// One 16-row output tile, K = KG*16, two interleaved accumulators.
+__device__ __forceinline__ f32x4 gemm1(f32x4 acc, const float4* __restrict__ wp, const int KG, const float* xrow) {
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int kg = 0; kg < KG; kg += 2) {
+    const float4 x0 = *reinterpret_cast<const float4*>(xrow + 16 * kg);
+    const float4 x1 = *reinterpret_cast<const float4*>(xrow + 16 * kg + 16);
+    const float4 w0 = wp[(size_t)kg * 64];
+    const float4 w1 = wp[(size_t)kg * 64 + 64];
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, x0.x, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, x1.x, acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, x0.y, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, x1.y, acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, x0.z, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, x1.z, acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, x0.w, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, x1.w, acc2, 0, 0, 0);
+  }
+  return acc + acc2;
+}
+
+template <int UPW, int TPP>
+__global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int H = a.H, HP = a.HP, XP = a.XP, W = a.W, D = a.D, V = a.V, L = a.L, B = a.B, G = a.G, N = a.N;
+  const int KGH = a.KGH, UT = H / 16;
+  float* h_lds = reinterpret_cast<float*>(smem);       // [L][16][HP]
+  float* xtop = h_lds + (size_t)L * 16 * HP;             // [16][PMG_XTP]
+  float* xex = xtop + 16 * PMG_XTP;                      // [16][XP]
+  int* misc = reinterpret_cast<int*>(xex + 16 * XP);     // [0..15] token, [16] all-done flag
+  float* lat = reinterpret_cast<float*>(misc + 32);      // decode only: [16][Z+8]
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int b = lane & 15, q = lane >> 4;
+  const int g = blockIdx.x;
+  const int row0 = g * PMG_ROWS;
+  const bool teacher = (a.mode == PMG_FWD_TEACHER);
+  const bool decode = (a.mode == PMG_FWD_DECODE);
+  const bool stepm = (a.mode == PMG_FWD_STEP);
+  const bool keep = teacher;  // keep per-step history for the backward
+
+  // ---------------------------------------------------------------- init
+  for (int idx = tid; idx < 16 * PMG_XTP; idx += PMG_THREADS) xtop[idx] = 0.0f;
+  if (tid < 32) misc[tid] = 0;
+  if (decode) {
+    // h0 = latent_to_hidden(latent): same value for every layer (reinforce.py:160-170 path)
+    const int ZP = a.Z + 8;
+    for (int idx = tid; idx < 16 * a.Z; idx += PMG_THREADS) {
+      const int bb = idx / a.Z, k = idx - bb * a.Z;
+      lat[bb * ZP + k] = (row0 + bb < B) ? a.latent[(size_t)(row0 + bb) * a.Z + k] : 0.0f;
+    }
+    __syncthreads();
+    for (int t = wave; t < UT; t += PMG_WAVES) {
+      f32x4 acc = ld4(a.b_l2h + 16 * t + 4 * q);
+      acc = gemm1(acc, a.L2Hp + ((size_t)t * (a.Z / 16)) * 64 + lane, a.Z / 16, lat + b * ZP + 4 * q);
+      for (int l = 0; l < L; ++l) st4(&h_lds[(size_t)(l * 16 + b) * HP + 16 * t + 4 * q], acc);
+    }
+  } else {
+    for (int idx = tid; idx < L * 16 * H; idx += PMG_THREADS) {
+      const int l = idx / (16 * H);
+      const int rem = idx - l * 16 * H;
+      const int bb = rem / H, k = rem - bb * H;
+      const float v = (row0 + bb < B) ? a.h0[((size_t)l * B + row0 + bb) * H + k] : 0.0f;
+      h_lds[(size_t)(l * 16 + bb) * HP + k] = v;
+    }
+  }
+  if (tid < 16) {
+    int t0 = a.start_tok;
+    if (!decode) t0 = (row0 + tid < B) ? (int)a.tok_in[row0 + tid] : 0;
+    misc[tid] = t0;
+  }
+  bool s_zero = true;  // stack entering step 0 is all zeros
+  if (stepm && a.stack_in != nullptr) {
+    s_zero = false;
+    float* S0 = a.SB + (size_t)g * a.SW;
+    for (int idx = tid; idx < D * W * 16; idx += PMG_THREADS) {
+      const int bb = idx & 15;
+      const int dw = idx >> 4;
+      S0[idx] = (row0 + bb < B) ? a.stack_in[(size_t)(row0 + bb) * D * W + dw] : 0.0f;
+    }
+  }
+  __syncthreads();
+  if (keep) {
+    for (int idx = tid; idx < L * 16 * H; idx += PMG_THREADS) {
+      const int l = idx / (16 * H);
+      const int rem = idx - l * 16 * H;
+      const int k = rem >> 4, bb = rem & 15;
+      a.HH[l][((size_t)g * H + k) * 16 + bb] = h_lds[(size_t)(l * 16 + bb) * HP + k];
+    }
+  }
+
+  // sampling state (meaningful in wave 0 only)
+  bool finished = false;
+  int mylen = N;
+
+  f32x4 ar[UPW], az[UPW], ai[UPW], ah[UPW];
+
+  for (int i = 0;; ++i) {
+    // ------------------------------------------------------------ extras GEMM
+    {
+      const float* xrow = h_lds + (size_t)((L - 1) * 16 + b) * HP + 4 * q;
+      for (int xt = wave; xt < a.NXT; xt += PMG_WAVES) {
+        f32x4 acc = ld4(a.BX + 16 * xt + 4 * q);
+        acc = gemm1(acc, a.WXp + ((size_t)xt * KGH) * 64 + lane, KGH, xrow);
+        st4(&xex[b * XP + 16 * xt + 4 * q], acc);
+      }
+    }
+    __syncthreads();  // B1
+
+    // ------------------------------------------------------------ consume logits of step i-1
+    if (i >= 1 && wave == 0) {
+      const int bb = lane >> 2, s = lane & 3;
+      const int row = row0 + bb;
+      const bool rowok = row < B;
+      const float* lg = xex + bb * XP + 3 + W;
+      const int CH = (V + 3) >> 2;
+      const int v0 = s * CH;
+      const int v1 = (v0 + CH < V) ? v0 + CH : V;
+      const int lbase = lane & ~3;
+      if (!decode) {
+        float m = -INFINITY;
+        for (int v = v0; v < v1; ++v) m = fmaxf(m, lg[v]);
+        m = fmaxf(m, __shfl_xor(m, 1));
+        m = fmaxf(m, __shfl_xor(m, 2));
+        float cs = 0.0f;
+        for (int v = v0; v < v1; ++v) cs += expf(lg[v] - m);
+        const float c0 = __shfl(cs, lbase), c1 = __shfl(cs, lbase + 1), c2 = __shfl(cs, lbase + 2),
+                    c3 = __shfl(cs, lbase + 3);
+        const float total = ((c0 + c1) + c2) + c3;
+        if (teacher) {
+          const int y = rowok ? (int)a.tok_in[(size_t)i * B + row] : 0;
+          if (y >= v0 && y < v1) {
+            const float lp = (lg[y] - m) - logf(total);
+            a.LP[((size_t)(i - 1) * G + g) * 16 + bb] = lp;
+            if (rowok) a.logp_out[(size_t)(i - 1) * B + row] = lp;
+          }
+          float* pr = a.PR + ((size_t)(i - 1) * G + g) * a.VP * 16;
+          const float inv = 1.0f / total;
+          for (int v = v0; v < v1; ++v) pr[v * 16 + bb] = expf(lg[v] - m) * inv;
+          if (s == 0) misc[bb] = y;
+        } else if (a.logits_out != nullptr && rowok) {
+          for (int v = v0; v < v1; ++v) a.logits_out[(size_t)row * V + v] = lg[v];
+        }
+      } else {
+        const bool greedy = !(a.temperature > 0.0f);
+        int tok;
+        if (greedy) {
+          float bv = -INFINITY; int bi = 0x7fffffff;
+          for (int v = v0; v < v1; ++v) { const float x = lg[v]; if (x > bv) { bv = x; bi = v; } }
+#pragma unroll
+          for (int o = 1; o <= 2; o <<= 1) {
+            const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+          }
+          tok = bi;
+        } else {
+          const float T = a.temperature;
+          float m = -INFINITY;
+          for (int v = v0; v < v1; ++v) m = fmaxf(m, lg[v] / T);
+          m = fmaxf(m, __shfl_xor(m, 1));
+          m = fmaxf(m, __shfl_xor(m, 2));
+          float cs = 0.0f;
+          for (int v = v0; v < v1; ++v) cs += expf(lg[v] / T - m);
+          const float c0 = __shfl(cs, lbase), c1 = __shfl(cs, lbase + 1), c2 = __shfl(cs, lbase + 2),
+                      c3 = __shfl(cs, lbase + 3);
+          const float total = ((c0 + c1) + c2) + c3;
+          const float u = pmg_uniform(a.seed, (uint64_t)(a.seq_base + row), a.offset + (uint64_t)(i - 1));
+          const float target = u * total;
+          const float pre = (s == 0) ? 0.0f : (s == 1) ? c0 : (s == 2) ? (c0 + c1) : ((c0 + c1) + c2);
+          const bool cond = (v0 < v1) && (target < pre + cs);
+          const unsigned long long bal = __ballot(cond);
+          const unsigned m4 = (unsigned)((bal >> lbase) & 0xFull);
+          const int sel = m4 ? (__ffs(m4) - 1) : -1;
+          int cand = V - 1;
+          if (sel == s) {
+            cand = v1 - 1;
+            float run = pre;
+            for (int v = v0; v < v1; ++v) {
+              run += expf(lg[v] / T - m);
+              if (target < run) { cand = v; break; }
+            }
+          }
+          tok = __shfl(cand, lbase + (sel < 0 ? 0 : sel));
+        }
+        if (rowok && s == 0) a.tok_out[(size_t)row * N + (i - 1)] = tok;
+        if (!finished && tok == a.stop_tok) { finished = true; mylen = i - 1; }
+        if (s == 0) misc[bb] = tok;
+        const bool alld = __all(finished || !rowok);
+        if (lane == 0) misc[16] = (alld && !(a.flags & PMG_FLAG_NO_EARLY_EXIT)) ? 1 : 0;
+      }
+    }
+    if (i == N) break;
+
+    // ------------------------------------------------------------ stack update
+    {
+      const int ncol = W * 4;
+      int dsplit = PMG_THREADS / ncol;
+      if (dsplit < 1) dsplit = 1;
+      if (dsplit > D) dsplit = D;
+      const int dch = (D + dsplit - 1) / dsplit;
+      const int slot_old = keep ? i : (i & 1);
+      const int slot_new = keep ? i + 1 : ((i + 1) & 1);
+      const float* Sold = a.SB + ((size_t)slot_old * G + g) * a.SW;
+      float* Snew = a.SB + ((size_t)slot_new * G + g) * a.SW;
+      const bool zero_old = (i == 0) && s_zero;
+      for (int item = tid; item < ncol * dsplit; item += PMG_THREADS) {
+        const int bq = item & 3;
+        const int cw = item >> 2;
+        const int w = cw % W;
+        const int part = cw / W;
+        const int d0 = part * dch;
+        const int d1 = (d0 + dch < D) ? d0 + dch : D;
+        if (d0 >= d1) continue;
+        f32x4 apush, apop, anoop, pv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float* cx = xex + (4 * bq + j) * XP;
+          const float c0 = cx[0], c1 = cx[1], c2 = cx[2];
+          const float m = fmaxf(c0, fmaxf(c1, c2));
+          const float e0 = expf(c0 - m), e1 = expf(c1 - m), e2 = expf(c2 - m);
+          const float inv = 1.0f / ((e0 + e1) + e2);
+          apush[j] = e0 * inv; apop[j] = e1 * inv; anoop[j] = e2 * inv;
+          pv[j] = tanhf(cx[3 + w]);
+        }
+        if (keep && part == 0) {
+          if (w == 0) {
+            float* ct = a.CT + ((size_t)i * G + g) * 64;
+            st4(ct + 0 * 16 + 4 * bq, apush);
+            st4(ct + 1 * 16 + 4 * bq, apop);
+            st4(ct + 2 * 16 + 4 * bq, anoop);
+          }
+          st4(a.PV + ((size_t)i * G + g) * 1024 + w * 16 + 4 * bq, pv);
+        }
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 prev = (d0 == 0) ? pv : (zero_old ? zero4 : ld4(Sold + ((size_t)(d0 - 1) * W + w) * 16 + 4 * bq));
+        f32x4 cur = zero_old ? zero4 : ld4(Sold + ((size_t)d0 * W + w) * 16 + 4 * bq);
+        for (int d = d0; d < d1; ++d) {
+          const f32x4 nxt = (d + 1 < D && !zero_old) ? ld4(Sold + ((size_t)(d + 1) * W + w) * 16 + 4 * bq) : zero4;
+          const f32x4 nw = anoop * cur + apush * prev + apop * nxt;
+          st4(Snew + ((size_t)d * W + w) * 16 + 4 * bq, nw);
+          if (d == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xtop[(4 * bq + j) * PMG_XTP + w] = nw[j];
+            if (keep) st4(a.TP + ((size_t)i * G + g) * 1024 + w * 16 + 4 * bq, nw);
+          }
+          prev = cur;
+          cur = nxt;
+        }
+      }
+    }
+
+    // ------------------------------------------------------------ layer 0: gh GEMM
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) {
+      const int j0 = 16 * (wave * UPW + u) + 4 * q;
+      ar[u] = ld4(a.BG[0] + 0 * H + j0);
+      az[u] = ld4(a.BG[0] + 1 * H + j0);
+      ai[u] = ld4(a.BG[0] + 2 * H + j0);
+      ah[u] = ld4(a.BG[0] + 3 * H + j0);
+    }
+    gemm3<UPW, TPP>(ar, az, ah, a.WHHp[0], KGH, h_lds + (size_t)b * HP + 4 * q, wave, lane);
+    __syncthreads();  // B2: stack top + token visible; every read of h_lds[0] (old) is done
+
+    if (decode && misc[16]) {
+      // every row of this group has emitted stop_tok: fill the tail and leave
+      for (int idx = tid; idx < 16 * (N - i); idx += PMG_THREADS) {
+        const int bb = idx / (N - i), t = i + (idx - bb * (N - i));
+        if (row0 + bb < B) a.tok_out[(size_t)(row0 + bb) * N + t] = a.stop_tok;
+      }
+      break;
+    }
+
+    // ------------------------------------------------------------ layer 0: stack-top GEMM, table, gates
+    gemm3<UPW, TPP>(ar, az, ai, a.WIHp[0], PMG_KS / 16, xtop + b * PMG_XTP + 4 * q, wave, lane);
+    {
+      const int tok = misc[b];
+      const float* gt = a.GTAB + (size_t)tok * 3 * H;
+#pragma unroll
+      for (int u = 0; u < UPW; ++u) {
+        const int ug = wave * UPW + u;
+        const int j0 = 16 * ug + 4 * q;
+        float* hp_ptr = &h_lds[(size_t)b * HP + j0];
+        const f32x4 hp = ld4(hp_ptr);
+        const f32x4 vr = ar[u] + ld4(gt + j0);
+        const f32x4 vz = az[u] + ld4(gt + H + j0);
+        const f32x4 vi = ai[u] + ld4(gt + 2 * H + j0);
+        const f32x4 vh = ah[u];
+        f32x4 r, z, n, hn;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          r[j] = pmg_sigmoid(vr[j]);
+          z[j] = pmg_sigmoid(vz[j]);
+          n[j] = tanhf(vi[j] + r[j] * vh[j]);
+          hn[j] = (hp[j] - n[j]) * z[j] + n[j];
+        }
+        st4(hp_ptr, hn);
+        if (keep) {
+          float* gp = a.GT[0] + ((((size_t)i * G + g) * UT + ug) * 4) * 256 + lane * 4;
+          st4(gp, r); st4(gp + 256, z); st4(gp + 512, n); st4(gp + 768, vh);
+          float* hh = a.HH[0] + (((size_t)(i + 1) * G + g) * H + j0) * 16 + b;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) hh[j * 16] = hn[j];
+        }
+      }
+    }
+    __syncthreads();  // B3
+
+    // ------------------------------------------------------------ layers 1..L-1
+    for (int l = 1; l < L; ++l) {
+#pragma unroll
+      for (int u = 0; u < UPW; ++u) {
+        const int j0 = 16 * (wave * UPW + u) + 4 * q;
+        ar[u] = ld4(a.BG[l] + 0 * H + j0);
+        az[u] = ld4(a.BG[l] + 1 * H + j0);
+        ai[u] = ld4(a.BG[l] + 2 * H + j0);
+        ah[u] = ld4(a.BG[l] + 3 * H + j0);
+      }
+      gemm3<UPW, TPP>(ar, az, ah, a.WHHp[l], KGH, h_lds + (size_t)(l * 16 + b) * HP + 4 * q, wave, lane);
+      gemm3<UPW, TPP>(ar, az, ai, a.WIHp[l], KGH, h_lds + (size_t)((l - 1) * 16 + b) * HP + 4 * q, wave, lane);
+      __syncthreads();  // every read of h_lds[l] (old) is done
+#pragma unroll
+      for (int u = 0; u < UPW; ++u) {
+        const int ug = wave * UPW + u;
+        const int j0 = 16 * ug + 4 * q;
+        float* hp_ptr = &h_lds[(size_t)(l * 16 + b) * HP + j0];
+        const f32x4 hp = ld4(hp_ptr);
+        f32x4 r, z, n, hn;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          r[j] = pmg_sigmoid(ar[u][j]);
+          z[j] = pmg_sigmoid(az[u][j]);
+          n[j] = tanhf(ai[u][j] + r[j] * ah[u][j]);
+          hn[j] = (hp[j] - n[j]) * z[j] + n[j];
+        }
+        st4(hp_ptr, hn);
+        if (keep) {
+          float* gp = a.GT[l] + ((((size_t)i * G + g) * UT + ug) * 4) * 256 + lane * 4;
+          st4(gp, r); st4(gp + 256, z); st4(gp + 512, n); st4(gp + 768, ah[u]);
+          float* hh = a.HH[l] + (((size_t)(i + 1) * G + g) * H + j0) * 16 + b;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) hh[j * 16] = hn[j];
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  if (decode && wave == 0) {
+    const int bb = lane >> 2, s = lane & 3;
+    if (s == 0 && row0 + bb < B) a.len_out[row0 + bb] = mylen;
+  }
+  if (a.h_out != nullptr) {
+    for (int idx = tid; idx < L * 16 * H; idx += PMG_THREADS) {
+      const int l = idx / (16 * H);
+      const int rem = idx - l * 16 * H;
+      const int bb = rem / H, k = rem - bb * H;
+      if (row0 + bb < B) a.h_out[((size_t)l * B + row0 + bb) * H + k] = h_lds[(size_t)(l * 16 + bb) * HP + k];
+    }
+  }
+  if (stepm && a.stack_out != nullptr) {
+    // step mode ran exactly one update: the new stack is in slot 1 (written by this workgroup)
+    __syncthreads();
+    const float* S1 = a.SB + ((size_t)1 * G + g) * a.SW;
+    for (int idx = tid; idx < D * W * 16; idx += PMG_THREADS) {
+      const int bb = idx & 15;
+      const int dw = idx >> 4;
+      if (row0 + bb < B) a.stack_out[(size_t)(row0 + bb) * D * W + dw] = S1[idx];
+    }
+  }
+}
+
+}  // namespace
+
+size_t pmg_fwd_lds_bytes(const FwdArgs* a) {
+  size_t fl = (size_t)a->L * 16 * a->HP + 16 * PMG_XTP + (size_t)16 * a->XP + 32;
+  if (a->mode == PMG_FWD_DECODE) fl += (size_t)16 * (a->Z + 8);
+  return fl * sizeof(float);
+}
+
+template <int UPW, int TPP>
+static hipError_t launch_fwd_t(const FwdArgs* a, hipStream_t st) {
+  const size_t lds = pmg_fwd_lds_bytes(a);
+  auto kern = pmg_fwd_kernel<UPW, TPP>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(a->G), dim3(PMG_THREADS), lds, st, *a);
+  return hipGetLastError();
+}
+
+hipError_t pmg_launch_fwd(const FwdArgs* a, hipStream_t st) {
+  switch (a->H) {
+    case 128: return launch_fwd_t<1, 1>(a, st);
+    case 256: return launch_fwd_t<2, 2>(a, st);
+    case 512: return launch_fwd_t<4, 2>(a, st);
+    case 1024: return launch_fwd_t<8, 2>(a, st);
+  }
+  return hipErrorInvalidValue;
+}

@@ -1,0 +1,103 @@
+// Argument blocks and launchers of the gfx950 kernels (internal; the public ABI is
+// include/pmg.h).
+#pragma once
+#include "pmg_common.h"
+
+// ------------------------------------------------------------------ packing
+enum PackKind {
+  PK_WX = 0,  // [ctrl | push | out] rows (natural order), K = H
+  PK_WHH,     // gate rows in (unit tile, gate) order, K = H
+  PK_WIS,     // layer-0 W_ih[:, E:E+W], gate rows in (unit tile, gate) order, K = 64 (zero padded)
+  PK_WIH,     // layer>0 W_ih, gate rows in (unit tile, gate) order, K = H
+  PK_L2H,     // latent_to_hidden, natural rows, K = Z
+  PK_WXT,     // transpose of the PK_WX source: out rows = H, reduction = NXT*16 (natural)
+  PK_WHHT,    // out rows = H, reduction over gate rows in backward chunk order
+  PK_WIST,    // out rows = 64 (stack width, padded), reduction over gate rows in chunk order
+  PK_WIHT,    // out rows = H (layer l-1 features), reduction over gate rows in chunk order
+};
+
+struct PackArgs {
+  int kind;
+  int tiles, KG;  // dst geometry: [tiles][KG][64][4]
+  int H, E, W, V, NX, UPW, Z;
+  const float* src;   // main source
+  const float* src2;  // PK_WX*: w_push
+  const float* src3;  // PK_WX*: w_out
+  float* dst;
+};
+
+struct AuxArgs {
+  int H, E, W, V, L, NX, NXT;
+  const float* b_ctrl; const float* b_push; const float* b_out;
+  const float* b_ih[PMG_MAX_LAYERS]; const float* b_hh[PMG_MAX_LAYERS];
+  const float* emb; const float* w_ih0;
+  float* BX; float* BG[PMG_MAX_LAYERS]; float* GTAB;
+};
+
+hipError_t pmg_launch_pack(const PackArgs* a, hipStream_t st);
+hipError_t pmg_launch_aux(const AuxArgs* a, hipStream_t st);
+
+// ------------------------------------------------------------------ forward
+#define PMG_FWD_DECODE 0
+#define PMG_FWD_TEACHER 1
+#define PMG_FWD_STEP 2
+
+struct FwdArgs {
+  int mode;   // PMG_FWD_*
+  int B, G, N;  // N decoder steps
+  int H, W, D, V, L, Z, NX, NXT, XP, HP, KGH, VP, SW;
+  int start_tok, stop_tok;
+  float temperature;
+  uint32_t flags;
+  uint64_t seed, offset;
+  int64_t seq_base;
+  // packed weights
+  const float4* WXp; const float* BX; const float* GTAB;
+  const float4* WHHp[PMG_MAX_LAYERS]; const float4* WIHp[PMG_MAX_LAYERS]; const float* BG[PMG_MAX_LAYERS];
+  const float4* L2Hp; const float* b_l2h;  // decode
+  // inputs
+  const float* latent;     // decode: [B][Z]
+  const float* h0;         // teacher/step: [L][B][H]
+  const int64_t* tok_in;   // teacher: [T][B]; step: [B]
+  const float* stack_in;   // step: [B][D][W] or NULL
+  // outputs
+  int64_t* tok_out;        // decode: [B][N]
+  int32_t* len_out;        // decode: [B]
+  float* logp_out;         // teacher: [N][B]
+  float* h_out;            // [L][B][H] or NULL
+  float* stack_out;        // step: [B][D][W] or NULL
+  float* logits_out;       // step: [B][V] or NULL
+  // state / history (workspace)
+  float* SB;               // stack slabs: decode/step 2 per group, teacher T per group ([slot][G][SW])
+  float* HH[PMG_MAX_LAYERS];  // teacher: [T][G][H][16]
+  float* GT[PMG_MAX_LAYERS];  // teacher: [T-1][G][UT][4][64][4]
+  float* CT; float* PV; float* TP; float* PR;
+  float* LP;               // teacher: [T-1][G][16] copy of logp for the backward's loss
+};
+
+hipError_t pmg_launch_fwd(const FwdArgs* a, hipStream_t st);
+size_t pmg_fwd_lds_bytes(const FwdArgs* a);
+
+// ------------------------------------------------------------------ backward
+struct BwdArgs {
+  int B, G, N;  // N = T-1 decoder steps
+  int H, W, D, V, L, NX, NXT, XP, KGH, VP, SW, UPW;
+  float scale;
+  const int64_t* tokens;  // [T][B]
+  const float* reward;    // [B]
+  // packed transposed weights
+  const float4* WXt; const float4* WHHt[PMG_MAX_LAYERS]; const float4* WIHt[PMG_MAX_LAYERS];
+  // history from the forward
+  const float* SB; const float* HH[PMG_MAX_LAYERS]; const float* GT[PMG_MAX_LAYERS];
+  const float* CT; const float* PV; const float* PR; const float* LP;
+  // outputs / scratch
+  float* DG[PMG_MAX_LAYERS];  // [N][G][4H][16]   rows: dr | dz | dn | dghn
+  float* DX;                  // [N+1][G][NXT*16][16]  rows: dctrl_p | dpush_p | dlogits_{p-1}
+  float* DS;                  // [2][G][SW] stack-gradient ping-pong
+  float* DHC;                 // [G][L][UT][64][4] hidden-gradient carry (D layout)
+  float* grad_h0;             // [L][B][H]
+  float* LOSSP;               // [G] loss partials
+};
+
+hipError_t pmg_launch_bwd(const BwdArgs* a, hipStream_t st);
+size_t pmg_bwd_lds_bytes(const BwdArgs* a);

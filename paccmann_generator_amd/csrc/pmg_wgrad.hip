@@ -1,0 +1,414 @@
+// Weight gradients of the REINFORCE step: one large-K "row-slab GEMM".
+//
+// The backward recurrence leaves, per time step p and row group g (16 sequences), the
+// gate/extras gradients as slabs [row][16] and the forward left the activations as
+// slabs [col][16].  Every parameter gradient is
+//     C[row][col] = sum_{p,g} sum_{b<16} A(p,g)[row][b] * B(p,g)[col][b]
+// i.e. a GEMM whose reduction runs over all B*T tokens.  Both operands are contiguous
+// along the reduction inside a slab, so a lane's four reduction values are one
+// dwordx4 load and feed four v_mfma_f32_16x16x4_f32 directly -- no LDS transpose.
+//
+// Jobs (reference: the autograd of reinforce_omics.py:322-335 w.r.t. each parameter):
+//   HH[l]  dW_hh[l]      = [dr|dz|dghn]^T  h^l_{p-1}
+//   IH[l]  dW_ih[l>0]    = [dr|dz|dn]^T    h^{l-1}_p
+//   IS     dW_ih[0][:,E:]= [dr|dz|dn]^T    stack_top_p
+//   TAB    dGTAB         = [dr|dz|dn]^T    onehot(tok_p)   -> embedding, W_ih[0][:, :E]
+//   X      d[W_ctrl;W_push;W_out] = [dctrl_p|dpush_p|dlogits_{p-1}]^T h^{top}_{p-1}
+// Bias gradients are the row sums of the A operands.
+// Split-K over slabs into per-split partial tiles, then a deterministic reduce and a
+// small finalize kernel that writes torch-layout gradients.
+#include "pmg_kernels.h"
+#include <string.h>
+
+#define WG_TM 128
+#define WG_TN 128
+#define WG_THREADS 256
+#define WG_MAXJOBS (2 + 2 * PMG_MAX_LAYERS + 1)
+
+struct WJob {
+  const float* A;   // slabs [P][G][a_rows][16]
+  const float* B;   // slabs [P(+shift)][G][b_rows][16]  (NULL: one-hot of tokens)
+  int a_rows;       // rows of one A slab
+  int skip_mid;     // 1: job row r >= 2H maps to slab row r + H (dgh: skip the dn piece)
+  int b_rows;       // rows of one B slab
+  int b_pshift;     // time shift of the B slabs
+  int rows, cols;   // logical C size
+  int row_tiles, col_tiles;
+  int tile0;        // first global tile index
+  int rs0;          // offset of this job's row sums in the row-sum vector
+  int P;            // time slabs
+  size_t c_off;     // offset of the dense C in the accumulator region
+};
+
+struct WgradArgs {
+  int njobs, total_tiles, total_rs, S;
+  int G, B, H;
+  const int64_t* tokens;
+  WJob jobs[WG_MAXJOBS];
+  float* partial;   // [S][total_tiles][128*128]
+  float* rs_partial;  // [S][total_rs]
+  float* dense;     // accumulators
+};
+
+namespace {
+
+__global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArgs a) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int n16 = lane & 15, q = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int s = blockIdx.x / a.total_tiles;
+  const int t = blockIdx.x - s * a.total_tiles;
+  int ji = 0;
+  for (int k = 1; k < a.njobs; ++k)
+    if (t >= a.jobs[k].tile0) ji = k;
+  const WJob& jb = a.jobs[ji];
+  const int tl = t - jb.tile0;
+  const int rt = tl / jb.col_tiles, ct = tl - rt * jb.col_tiles;
+  const int r0 = rt * WG_TM + wr * 64;
+  const int c0 = ct * WG_TN + wc * 64;
+  const int H = a.H, G = a.G;
+
+  bool va[4], vb[4];
+  size_t aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + 16 * i;
+    va[i] = r < jb.rows;
+    int rr = r + n16;
+    if (jb.skip_mid && rr >= 2 * H) rr += H;
+    aoff[i] = (size_t)rr * 16 + 4 * q;
+    const int c = c0 + 16 * i;
+    vb[i] = c < jb.cols;
+    boff[i] = (size_t)(c + n16) * 16 + 4 * q;
+  }
+  const bool onehot = (jb.B == nullptr);
+
+  const int nslab = jb.P * G;
+  const int per = (nslab + a.S - 1) / a.S;
+  const int sl0 = s * per;
+  const int sl1 = (sl0 + per < nslab) ? sl0 + per : nslab;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float rsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto load_a = [&](int sl, float4 (&fa)[4]) {
+    const float* As = jb.A + (size_t)sl * jb.a_rows * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = va[i] ? *reinterpret_cast<const float4*>(As + aoff[i]) : zero;
+  };
+  auto load_b = [&](int sl, float4 (&fb)[4]) {
+    if (!onehot) {
+      const float* Bs = jb.B + ((size_t)sl + (size_t)jb.b_pshift * G) * jb.b_rows * 16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = vb[j] ? *reinterpret_cast<const float4*>(Bs + boff[j]) : zero;
+    } else {
+      const int p = sl / G, g = sl - p * G;
+      int tk[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int row = g * 16 + 4 * q + c;
+        tk[c] = (row < a.B) ? (int)a.tokens[(size_t)p * a.B + row] : -1;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = c0 + 16 * j + n16;
+        fb[j] = make_float4(tk[0] == col ? 1.f : 0.f, tk[1] == col ? 1.f : 0.f, tk[2] == col ? 1.f : 0.f,
+                            tk[3] == col ? 1.f : 0.f);
+      }
+    }
+  };
+
+  if (sl0 < sl1) {
+    float4 fa[4], fb[4];
+    load_a(sl0, fa);
+    load_b(sl0, fb);
+    for (int sl = sl0; sl < sl1; ++sl) {
+      float4 na[4], nb[4];
+      const int sn = (sl + 1 < sl1) ? sl + 1 : sl;
+      load_a(sn, na);
+      load_b(sn, nb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rsum[i] += (fa[i].x + fa[i].y) + (fa[i].z + fa[i].w);
+#define WG_STEP(C)                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)        \
+      if (va[i] && vb[j]) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].C, fb[j].C, acc[i][j], 0, 0, 0);
+      WG_STEP(x) WG_STEP(y) WG_STEP(z) WG_STEP(w)
+#undef WG_STEP
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { fa[i] = na[i]; fb[i] = nb[i]; }
+    }
+  }
+
+  // partial tile: [128][128], element (row_local, col_local)
+  float* pt = a.partial + ((size_t)s * a.total_tiles + t) * (WG_TM * WG_TN);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int rl = wr * 64 + 16 * i + 4 * q + rg;
+        const int cl = wc * 64 + 16 * j + n16;
+        pt[rl * WG_TN + cl] = acc[i][j][rg];
+      }
+  // row sums (bias gradients): only the first column tile's wc==0 waves own them
+  if (ct == 0 && wc == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = rsum[i];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      const int r = r0 + 16 * i + n16;
+      if (q == 0 && r < jb.rows) a.rs_partial[(size_t)s * a.total_rs + jb.rs0 + r] = v;
+    }
+  }
+}
+
+// dense[job] = sum over splits of the partial tiles; row sums likewise.
+__global__ void pmg_wgrad_reduce_kernel(const WgradArgs a) {
+  size_t total = 0;
+  for (int k = 0; k < a.njobs; ++k) total += (size_t)a.jobs[k].rows * a.jobs[k].cols;
+  const size_t total_all = total + a.total_rs;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total_all;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    if (idx < total) {
+      size_t rem = idx;
+      int ji = 0;
+      for (; ji < a.njobs; ++ji) {
+        const size_t sz = (size_t)a.jobs[ji].rows * a.jobs[ji].cols;
+        if (rem < sz) break;
+        rem -= sz;
+      }
+      const WJob& jb = a.jobs[ji];
+      const int r = (int)(rem / jb.cols), c = (int)(rem % jb.cols);
+      const int t = jb.tile0 + (r / WG_TM) * jb.col_tiles + (c / WG_TN);
+      const size_t e = (size_t)(r % WG_TM) * WG_TN + (c % WG_TN);
+      float sum = 0.0f;
+      for (int s = 0; s < a.S; ++s) sum += a.partial[((size_t)s * a.total_tiles + t) * (WG_TM * WG_TN) + e];
+      a.dense[jb.c_off + rem] = sum;
+    } else {
+      const size_t r = idx - total;
+      float sum = 0.0f;
+      for (int s = 0; s < a.S; ++s) sum += a.rs_partial[(size_t)s * a.total_rs + r];
+      a.dense[a.jobs[0].c_off + total + r] = sum;  // row sums live right after the dense matrices
+    }
+  }
+}
+
+struct FinArgs {
+  int H, E, W, V, L, NX, NXT, VP, G, pad_idx, accumulate;
+  const float* dense;
+  size_t c_hh[PMG_MAX_LAYERS], c_ih[PMG_MAX_LAYERS], c_tab, c_x;  // c_ih[0] = IS job
+  size_t rs_hh[PMG_MAX_LAYERS], rs_gi[PMG_MAX_LAYERS], rs_x;       // absolute offsets in dense
+  const float* emb; const float* w_ih0;
+  const float* lossp;
+  pmg_grads g;
+  float* loss_out;
+};
+
+__device__ __forceinline__ void put(float* p, float v, int acc) { *p = acc ? (*p + v) : v; }
+
+__global__ void pmg_finalize_kernel(const FinArgs a) {
+  const int H = a.H, E = a.E, W = a.W, V = a.V, L = a.L;
+  const size_t n_emb = (size_t)V * E;
+  const size_t n_wih0 = (size_t)3 * H * (E + W);
+  const size_t n_whh = (size_t)3 * H * H;
+  const size_t n_b = (size_t)3 * H;
+  const size_t n_x = (size_t)a.NX * H + a.NX;  // ctrl/push/out weights + biases
+  size_t total = n_emb + n_wih0 + (size_t)(L - 1) * n_whh + (size_t)L * n_whh + (size_t)2 * L * n_b + n_x + 1;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    size_t r = idx;
+    if (r < n_emb) {
+      const int v = (int)(r / E), e = (int)(r % E);
+      float s = 0.0f;
+      if (v != a.pad_idx) {
+        const float* tab = a.dense + a.c_tab;  // [3H][VP]
+        for (int n = 0; n < 3 * H; ++n) s = fmaf(tab[(size_t)n * a.VP + v], a.w_ih0[(size_t)n * (E + W) + e], s);
+      }
+      put(a.g.embedding + r, s, a.accumulate);
+      continue;
+    }
+    r -= n_emb;
+    if (r < n_wih0) {
+      const int n = (int)(r / (E + W)), e = (int)(r % (E + W));
+      float s = 0.0f;
+      if (e < E) {
+        const float* tab = a.dense + a.c_tab + (size_t)n * a.VP;
+        for (int v = 0; v < V; ++v) s = fmaf(tab[v], a.emb[(size_t)v * E + e], s);
+      } else {
+        s = a.dense[a.c_ih[0] + (size_t)n * PMG_KS + (e - E)];
+      }
+      put(a.g.w_ih[0] + r, s, a.accumulate);
+      continue;
+    }
+    r -= n_wih0;
+    bool done = false;
+    for (int l = 1; l < L && !done; ++l) {
+      if (r < n_whh) { put(a.g.w_ih[l] + r, a.dense[a.c_ih[l] + r], a.accumulate); done = true; }
+      else r -= n_whh;
+    }
+    if (done) continue;
+    for (int l = 0; l < L && !done; ++l) {
+      if (r < n_whh) { put(a.g.w_hh[l] + r, a.dense[a.c_hh[l] + r], a.accumulate); done = true; }
+      else r -= n_whh;
+    }
+    if (done) continue;
+    for (int l = 0; l < L && !done; ++l) {
+      if (r < n_b) { put(a.g.b_ih[l] + r, a.dense[a.rs_gi[l] + r], a.accumulate); done = true; }
+      else r -= n_b;
+    }
+    if (done) continue;
+    for (int l = 0; l < L && !done; ++l) {
+      if (r < n_b) { put(a.g.b_hh[l] + r, a.dense[a.rs_hh[l] + r], a.accumulate); done = true; }
+      else r -= n_b;
+    }
+    if (done) continue;
+    if (r < (size_t)a.NX * H) {
+      const int n = (int)(r / H), k = (int)(r % H);
+      const float v = a.dense[a.c_x + r];
+      if (n < 3) put(a.g.w_ctrl + (size_t)n * H + k, v, a.accumulate);
+      else if (n < 3 + W) put(a.g.w_push + (size_t)(n - 3) * H + k, v, a.accumulate);
+      else put(a.g.w_out + (size_t)(n - 3 - W) * H + k, v, a.accumulate);
+      continue;
+    }
+    r -= (size_t)a.NX * H;
+    if (r < (size_t)a.NX) {
+      const int n = (int)r;
+      const float v = a.dense[a.rs_x + n];
+      if (n < 3) put(a.g.b_ctrl + n, v, a.accumulate);
+      else if (n < 3 + W) put(a.g.b_push + (n - 3), v, a.accumulate);
+      else put(a.g.b_out + (n - 3 - W), v, a.accumulate);
+      continue;
+    }
+    // the loss
+    float s = 0.0f;
+    for (int g = 0; g < a.G; ++g) s += a.lossp[g];
+    *a.loss_out = s;
+  }
+}
+
+struct JobPlan {
+  WgradArgs w;
+  FinArgs f;
+  size_t dense_floats, partial_floats, rs_partial_floats;
+};
+
+int choose_splits(const PmgDims& d, int total_tiles) {
+  const long slabs = (long)(d.T - 1) * d.G;
+  long S = 2048 / (total_tiles > 0 ? total_tiles : 1);
+  if (S < 1) S = 1;
+  if (S > 64) S = 64;
+  const long maxS = (slabs + 3) / 4;  // at least ~4 slabs per split
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  return (int)S;
+}
+
+void build_plan(const PmgDims& d, JobPlan* P) {
+  memset(P, 0, sizeof(*P));
+  WgradArgs& w = P->w;
+  FinArgs& f = P->f;
+  const int H = d.H, N = d.T - 1;
+  int nj = 0, tile = 0, rs = 0;
+  size_t coff = 0;
+  auto add = [&](int rows, int cols, int a_rows, int skip_mid, int b_rows, int b_pshift, int Psl) -> WJob& {
+    WJob& j = w.jobs[nj++];
+    j.rows = rows; j.cols = cols; j.a_rows = a_rows; j.skip_mid = skip_mid; j.b_rows = b_rows;
+    j.b_pshift = b_pshift; j.P = Psl;
+    j.row_tiles = pmg_ceil_div(rows, WG_TM); j.col_tiles = pmg_ceil_div(cols, WG_TN);
+    j.tile0 = tile; tile += j.row_tiles * j.col_tiles;
+    j.rs0 = rs; rs += rows;
+    j.c_off = coff; coff += (size_t)rows * cols;
+    return j;
+  };
+  // job order is fixed; pointers are filled by the caller
+  for (int l = 0; l < d.L; ++l) { WJob& j = add(3 * H, H, 4 * H, 1, H, 0, N); f.c_hh[l] = j.c_off; f.rs_hh[l] = j.rs0; }
+  for (int l = 0; l < d.L; ++l) {
+    WJob& j = (l == 0) ? add(3 * H, PMG_KS, 4 * H, 0, PMG_KS, 0, N) : add(3 * H, H, 4 * H, 0, H, 1, N);
+    f.c_ih[l] = j.c_off; f.rs_gi[l] = j.rs0;
+  }
+  { WJob& j = add(3 * H, d.VP, 4 * H, 0, 0, 0, N); f.c_tab = j.c_off; }
+  { WJob& j = add(d.NXT * 16, H, d.NXT * 16, 0, H, 0, N + 1); f.c_x = j.c_off; f.rs_x = j.rs0; }
+  w.njobs = nj; w.total_tiles = tile; w.total_rs = rs;
+  w.S = choose_splits(d, tile);
+  w.G = d.G; w.B = d.B; w.H = H;
+  // row sums are stored right behind the dense matrices
+  for (int l = 0; l < d.L; ++l) { f.rs_hh[l] += coff; f.rs_gi[l] += coff; }
+  f.rs_x += coff;
+  P->dense_floats = coff + rs;
+  P->partial_floats = (size_t)w.S * tile * (WG_TM * WG_TN);
+  P->rs_partial_floats = (size_t)w.S * rs;
+}
+
+}  // namespace
+
+size_t pmg_wgrad_acc_floats(const PmgDims& d) {
+  JobPlan P;
+  build_plan(d, &P);
+  return P.dense_floats;
+}
+
+size_t pmg_wgrad_partial_floats(const PmgDims& d) {
+  JobPlan P;
+  build_plan(d, &P);
+  return P.partial_floats + P.rs_partial_floats + 64;
+}
+
+hipError_t pmg_run_wgrad(const PmgDims& d, const PmgLayout& lay, float* ws, const pmg_weights* wts,
+                         const int64_t* tokens, uint32_t flags, const pmg_grads* grads, float* loss_out,
+                         hipStream_t st) {
+  JobPlan P;
+  build_plan(d, &P);
+  WgradArgs& w = P.w;
+  w.tokens = tokens;
+  w.dense = ws + lay.WG;
+  w.partial = ws + lay.WGP;
+  w.rs_partial = ws + lay.WGP + ((P.partial_floats + 63) & ~(size_t)63);
+  int k = 0;
+  for (int l = 0; l < d.L; ++l) { w.jobs[k].A = ws + lay.DG[l]; w.jobs[k].B = ws + lay.HH[l]; ++k; }
+  for (int l = 0; l < d.L; ++l) {
+    w.jobs[k].A = ws + lay.DG[l];
+    w.jobs[k].B = (l == 0) ? ws + lay.TP : ws + lay.HH[l - 1];
+    ++k;
+  }
+  w.jobs[k].A = ws + lay.DG[0]; w.jobs[k].B = nullptr; ++k;
+  w.jobs[k].A = ws + lay.DX; w.jobs[k].B = ws + lay.HH[d.L - 1]; ++k;
+
+  hipLaunchKernelGGL(pmg_wgrad_kernel, dim3(w.total_tiles * w.S), dim3(WG_THREADS), 0, st, w);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  {
+    size_t total = P.dense_floats;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pmg_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, w);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  FinArgs& f = P.f;
+  f.H = d.H; f.E = d.E; f.W = d.W; f.V = d.V; f.L = d.L; f.NX = d.NX; f.NXT = d.NXT; f.VP = d.VP; f.G = d.G;
+  f.pad_idx = d.pad_idx; f.accumulate = (flags & PMG_FLAG_ACCUMULATE) ? 1 : 0;
+  f.dense = w.dense;
+  f.emb = wts->embedding; f.w_ih0 = wts->w_ih[0];
+  f.lossp = ws + lay.LOSSP;
+  f.g = *grads;
+  f.loss_out = loss_out;
+  {
+    const size_t H = d.H;
+    size_t total = (size_t)d.V * d.E + 3 * H * (d.E + d.W) + (size_t)(2 * d.L - 1) * 3 * H * H +
+                   (size_t)2 * d.L * 3 * H + (size_t)d.NX * H + d.NX + 1;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pmg_finalize_kernel, dim3(blocks), dim3(256), 0, st, f);
+    e = hipGetLastError();
+  }
+  return e;
+}
