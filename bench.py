@@ -1,0 +1,279 @@
+#!/usr/bin/env python
+"""Headline benchmark: sampled SMILES tokens/s for one decode + REINFORCE step.
+
+A "step" = one pass of the hot path over one batch of synthetic latents
+(BASELINE.json configs[1]: hidden 512, stack depth 50, batch 4096 per GPU, len 128, fp32):
+  1. sampling decode of B x T tokens                  (pmg_decode)
+  2. append 2 stop tokens, pad (device twin of reinforce.py:177-184 / pad_sequence)
+  3. h0 = latent_to_hidden(latent)                    (torch, autograd-connected)
+  4. teacher-forced log-probs                         (pmg_logprob_fwd)
+  5. reward-weighted BPTT + weight gradients          (pmg_reinforce_bwd)
+  6. N>1: one RCCL all-reduce of the flat gradient
+  7. clip_grad_norm_ + Adam                           (torch)
+Rewards are synthetic and resident (RDKit scoring stays on the host and is not part of
+the step).  Random-init weights, synthetic latents.
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 via
+python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+CONFIGS = {
+    'cfg1': dict(embedding_size=128, rnn_cell_size=256, vocab_size=60, stack_width=50, stack_depth=50,
+                 n_layers=1, latent_dim=256, pad_index=0, batch=64, length=100),
+    'cfg2': dict(embedding_size=128, rnn_cell_size=512, vocab_size=60, stack_width=50, stack_depth=50,
+                 n_layers=1, latent_dim=256, pad_index=0, batch=4096, length=128),
+    'cfg4': dict(embedding_size=128, rnn_cell_size=1024, vocab_size=60, stack_width=50, stack_depth=50,
+                 n_layers=2, latent_dim=256, pad_index=0, batch=4096, length=256),
+}
+START, STOP = 2, 3
+
+
+def flops_per_token(c):
+    """forward flops per (sequence, step)."""
+    H, E, W, D, V, L = (c['rnn_cell_size'], c['embedding_size'], c['stack_width'], c['stack_depth'],
+                        c['vocab_size'], c['n_layers'])
+    f = 0
+    for l in range(L):
+        i_l = (E + W) if l == 0 else H
+        f += 6 * H * (i_l + H)
+    return f + 6 * H + 2 * H * W + 5 * D * W + 2 * H * V
+
+
+class _Lang:
+    start_index = START
+    stop_index = STOP
+
+
+class _Log:
+    def info(self, *a, **k):
+        pass
+
+    warning = info
+
+
+def build_learner(cfg, device, process_group=None):
+    from paccmann_generator_amd import Generator, StackGRUDecoder
+    from paccmann_generator_amd.reinforce import Reinforce
+    torch.manual_seed(0)
+    dec = StackGRUDecoder(cfg)
+    dec = dec.to(device).eval()
+    gen = Generator(None, dec)
+    gen._associate_language(_Lang())
+    gen.seed(1234)
+    params = dict(generate_len=cfg['length'], temperature=0.8, clip_grad=0.1, learning_rate=3e-4,
+                  save_untrained=False)
+    learner = Reinforce(gen, None, params, 'bench', _Log(), is_valid=lambda s: True,
+                        reward_fn=None, process_group=process_group)
+    return learner
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """The CPU oracle driven through the reference's loop structure (generate +
+    policy_gradient), on a bounded sample of the same workload."""
+    from oracle import reinforce_loop as RL
+    from oracle.stack_gru import OracleGenerator, SamplingSearch, build_decoder
+    B = 64 if cfg['rnn_cell_size'] <= 512 else 16
+    T = cfg['length']
+    dec = build_decoder(cfg, seed=0)
+    gen = OracleGenerator(dec)
+    opt = RL.make_optimizer(dec, dict(learning_rate=3e-4))
+    torch.manual_seed(1)
+    latent = torch.randn(1, B, cfg['latent_dim'])
+    torch.manual_seed(2)
+    rewards = torch.rand(B).numpy()
+
+    def one():
+        mols = list(gen.generate(latent, torch.tensor([START]), torch.tensor([STOP]), T, SamplingSearch(0.8)))
+        nums = RL.append_stops(mols, STOP)
+        RL.policy_gradient_step(dec, opt, latent, nums, list(range(B)), rewards, lrps=1, clip_grad=0.1)
+
+    one()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 10:
+            break
+    return dict(value=B * T * n / el, unit='tokens/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{n} decode+REINFORCE steps of the eager-PyTorch oracle at B={B}, T={T} '
+                       f'(same model shape), {el:.1f}s')
+
+
+def time_phases(learner, cfg, latent, rewards, B, reps=3):
+    """Per-kernel durations with HIP events on the launch stream (torch's current stream)."""
+    import ctypes as C
+    from paccmann_generator_amd import _ffi, ops
+    from paccmann_generator_amd.reinforce import pad_rows_on_device
+    dec = learner.generator.decoder
+    w = dec.weights()
+    T = cfg['length']
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    out = {}
+    tok_len = {}
+
+    def f_dec():
+        tok_len['v'] = ops.decode(w, latent, START, STOP, T, temperature=0.8, seed=1, offset=0, early_exit=False)
+    out['decode'] = timed(f_dec)
+    tokens, lens = tok_len['v']
+    padded = pad_rows_on_device(tokens, lens, STOP, t_max=T + 2)
+    Tt = padded.shape[0]
+    with torch.no_grad():
+        h0 = dec.latent_to_hidden(latent.repeat(dec.n_layers, 1, 1)).contiguous()
+    shape = w.shape(B, Tt)
+    ws = torch.empty(_ffi.workspace_bytes(shape, _ffi.PMG_MODE_TRAIN), dtype=torch.uint8, device=latent.device)
+    wstruct, keep = w.struct(False)
+    logp = torch.empty(Tt - 1, B, dtype=torch.float32, device=latent.device)
+    grads = [torch.empty_like(p) for p in w.flat()]
+    gstruct, keep2 = _ffi.pack_weight_struct(_ffi.PmgGrads, ops.DecoderWeights.unflatten(grads, dec.n_layers),
+                                             dec.n_layers)
+    gh0 = torch.empty_like(h0)
+    loss = torch.empty(1, dtype=torch.float32, device=latent.device)
+    st = _ffi.current_stream()
+
+    def f_fwd():
+        _ffi.check(_ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(h0),
+                                            _ffi._ptr(logp), None, _ffi._ptr(ws), st), 'fwd')
+
+    def f_bwd(flags):
+        def f():
+            _ffi.check(_ffi.lib.pmg_reinforce_bwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded),
+                                                  _ffi._ptr(rewards), 1.0 / B, flags, C.byref(gstruct),
+                                                  _ffi._ptr(gh0), _ffi._ptr(loss), _ffi._ptr(ws), st), 'bwd')
+        return f
+    out['teacher_fwd'] = timed(f_fwd)
+    out['bptt'] = timed(f_bwd(_ffi.PMG_FLAG_SKIP_WGRAD))
+    out['wgrad'] = timed(f_bwd(_ffi.PMG_FLAG_ONLY_WGRAD))
+    out['_steps'] = dict(decode=T, teacher_fwd=Tt - 1, bptt=Tt - 1, wgrad=Tt - 1)
+    del ws
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--config', default='cfg2', choices=sorted(CONFIGS))
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config\'s)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-phases', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch N>1 with torch.distributed.run (one rank per GPU)')
+    import torch.distributed as dist
+    pg = None
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl')
+        pg = dist.group.WORLD
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+
+    cfg = dict(CONFIGS[args.config])
+    B = args.batch or cfg['batch']
+    T = cfg['length']
+    learner = build_learner(cfg, device, pg)
+    from paccmann_generator_amd.reinforce import pad_rows_on_device
+
+    # synthetic, resident inputs
+    torch.manual_seed(1 + rank)
+    latent = torch.randn(1, B, cfg['latent_dim'], device=device)
+    torch.manual_seed(2 + rank)
+    rewards = torch.rand(B, device=device)
+    valid_idx = torch.arange(B, device=device)
+
+    def step():
+        tokens, lens = learner.sample_tokens(latent, seq_index_base=rank * B, early_exit=False)
+        padded = pad_rows_on_device(tokens, lens, STOP, t_max=T + 2)
+        learner.learn(latent, padded, valid_idx, rewards, lrps=1, n_valid_global=B * world)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    ms_per_step = 1e3 * el / args.steps
+    tokens_per_s = world * B * T * args.steps / el
+    F = flops_per_token(cfg)
+
+    result = {
+        'metric': 'sampled SMILES tokens/sec (decode + REINFORCE step)',
+        'value': tokens_per_s, 'unit': 'tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{args.config}: omics-conditioned decode+REINFORCE, hidden {cfg["rnn_cell_size"]}, '
+                               f'stack {cfg["stack_depth"]}x{cfg["stack_width"]}, layers {cfg["n_layers"]}, '
+                               f'vocab {cfg["vocab_size"]}, emb {cfg["embedding_size"]}, latent {cfg["latent_dim"]}',
+                   'batch_per_gpu': B, 'global_batch': B * world, 'len': T, 'parallelism': f'dp{world}',
+                   'flop_per_token_fwd': F},
+        'step_roofline_frac': (tokens_per_s / world) * 3 * F / (PEAK_F32_MFMA_TFLOPS * 1e12),
+    }
+    if rank == 0:
+        if not args.no_phases:
+            ph = time_phases(learner, cfg, latent, rewards, B)
+            steps = ph.pop('_steps')
+            dom = max(ph, key=lambda k: ph[k])
+            ach = B * steps[dom] * F / (ph[dom] * 1e-3) / 1e12
+            result['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
+                                  'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                                  'ms': ph[dom]}
+            result['phase_ms'] = ph
+            result['phase_tflops'] = {k: B * steps[k] * F / (v * 1e-3) / 1e12 for k, v in ph.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(cfg)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -35,6 +35,8 @@ extern "C" {
 /* flags */
 #define PMG_FLAG_NO_EARLY_EXIT 1u /* decode: run all gen_len steps even after every row hit stop */
 #define PMG_FLAG_ACCUMULATE 2u    /* bwd: add into grad_out instead of overwriting it */
+#define PMG_FLAG_SKIP_WGRAD 4u    /* bwd, profiling aid: run the time recurrence only (grad_out untouched) */
+#define PMG_FLAG_ONLY_WGRAD 8u    /* bwd, profiling aid: redo the weight-gradient GEMM of the previous call */
 
 typedef void* pmg_stream; /* hipStream_t */
 

@@ -16,6 +16,8 @@ PMG_MODE_DECODE = 0
 PMG_MODE_TRAIN = 1
 PMG_FLAG_NO_EARLY_EXIT = 1
 PMG_FLAG_ACCUMULATE = 2
+PMG_FLAG_SKIP_WGRAD = 4
+PMG_FLAG_ONLY_WGRAD = 8
 PMG_ABI_VERSION = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -293,7 +293,7 @@ extern "C" int pmg_reinforce_bwd(const pmg_shape* s, const pmg_weights* w, const
   a.LP = base + lay.LP;
   a.DX = base + lay.DX; a.DS = base + lay.DS; a.DHC = base + lay.DHC; a.grad_h0 = grad_h0;
   a.LOSSP = base + lay.LOSSP;
-  HIPCHK(pmg_launch_bwd(&a, st));
-  HIPCHK(pmg_run_wgrad(d, lay, base, w, tokens, flags, grad_out, loss_out, st));
+  if (!(flags & PMG_FLAG_ONLY_WGRAD)) HIPCHK(pmg_launch_bwd(&a, st));
+  if (!(flags & PMG_FLAG_SKIP_WGRAD)) HIPCHK(pmg_run_wgrad(d, lay, base, w, tokens, flags, grad_out, loss_out, st));
   return PMG_OK;
 }

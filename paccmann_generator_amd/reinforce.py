@@ -1,0 +1,301 @@
+"""Host-side mirror of the reference's REINFORCE classes for the hot path only.
+
+Same constructor arguments, method names, argument meaning and return values as
+/root/reference/paccmann_generator/reinforce.py (``Reinforce``),
+reinforce_omics.py (``ReinforceOmic``) and reinforce_proteins.py
+(``ReinforceProtein``) for: ``get_smiles_from_latent``, ``encode_cell_line`` /
+``encode_protein``, ``policy_gradient``, ``reparameterize``, ``save`` / ``load``.
+What changed underneath: ``generator.generate`` is one fused HIP decode, and the
+teacher-forced Python loop + ``rl_loss.backward()`` (reinforce_omics.py:319-335) is
+one fused operator (ops.reinforce_loss).
+
+Out of scope here: the RDKit / toxsmi drug
+evaluators, the predictor networks, plotting.  The reward is therefore a pluggable
+host callable ``reward_fn(smiles_list, target) -> np.ndarray`` and molecule validity a
+pluggable ``is_valid(smiles) -> bool`` (defaults to RDKit's MolFromSmiles when RDKit
+is importable, as at reinforce.py:195).
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .decoder import SamplingSearch
+
+
+def _rdkit_validity():
+    try:
+        from rdkit import Chem  # type: ignore
+    except Exception:  # pragma: no cover - rdkit is absent in the build image
+        return None
+    return lambda s: Chem.MolFromSmiles(s, sanitize=True) is not None
+
+
+class Reinforce(object):
+
+    def __init__(self, generator, encoder, params, model_name, logger, is_valid: Optional[Callable] = None,
+                 reward_fn: Optional[Callable] = None, process_group=None):
+        """Same positional arguments as reinforce.py:16.  Keyword-only extras:
+
+        is_valid:      host validity check replacing Chem.MolFromSmiles (reinforce.py:195)
+        reward_fn:     host reward ``f(smiles, target) -> array`` (reinforce_omics.py:209-222)
+        process_group: torch.distributed group for data-parallel latent sharding
+        """
+        super(Reinforce, self).__init__()
+        self.generator = generator
+        self.generator.eval()
+        self.encoder = encoder
+        if self.encoder is not None:
+            self.encoder.eval()
+        self.logger = logger
+        self.device = self.generator.decoder.output_layer.weight.device
+        if self.device.type != 'cuda':
+            raise RuntimeError('paccmann_generator_amd needs the decoder on a GPU: there is no CPU path')
+
+        # reinforce.py:44-49: Adam over decoder parameters only
+        self.optimizer = torch.optim.Adam(
+            list(self.generator.decoder.parameters()),
+            lr=params.get('learning_rate', 0.0001),
+            eps=params.get('eps', 0.0001),
+            weight_decay=params.get('weight_decay', 0.00001),
+        )
+        self.model_name = model_name
+        self.model_path = os.path.join(params.get('model_folder', 'biased_models'), model_name)
+        self.weights_path = os.path.join(self.model_path, 'weights/{}')
+        self.is_valid = is_valid if is_valid is not None else _rdkit_validity()
+        self.reward_fn = reward_fn
+        self.process_group = process_group
+
+        # reinforce.py:59-77
+        if params.get('save_untrained', True):
+            if not os.path.isdir(self.model_path):
+                os.makedirs(os.path.join(self.model_path, 'weights'), exist_ok=True)
+                os.makedirs(os.path.join(self.model_path, 'results'), exist_ok=True)
+                self.save('generator_epoch_0.pt', 'encoder_epoch_0.pt')
+                with open(os.path.join(self.model_path, 'model_params.json'), 'w') as f:
+                    json.dump(params, f)
+            elif self.logger is not None:
+                self.logger.warning('Model exists already. Call model.load() to restore weights.')
+        self.update_params(params)
+
+    # reinforce.py:79-97 (evaluator construction is out of scope)
+    def update_params(self, params):
+        self.gamma = params.get('gamma', 0.99)
+        default_len = 100
+        predictor = getattr(self, 'predictor', None)
+        if predictor is not None and hasattr(predictor, 'params'):
+            default_len = predictor.params.get('smiles_padding_length', 102) - 2
+        self.generate_len = params.get('generate_len', default_len)
+        self.temperature = params.get('temperature', 0.8)
+        self.grad_clipping = params.get('clip_grad', None)
+
+    def reparameterize(self, mu, logvar):
+        """reinforce.py:99-111: noise-free."""
+        return mu
+
+    # ------------------------------------------------------------------ sampling
+    def _decoder_latent(self, latent):
+        """reinforce.py:160-161."""
+        if self.encoder is not None and \
+                self.generator.decoder.latent_dim == 2 * getattr(self.encoder, 'latent_size', -1):
+            latent = latent.repeat(1, 1, 2)
+        return latent
+
+    def sample_tokens(self, latent, seq_index_base: int = 0, early_exit: bool = True):
+        """Device-side half of get_smiles_from_latent: (tokens [B,generate_len], lengths [B])."""
+        lang = self.generator.smiles_language
+        return self.generator.generate_tokens(
+            self._decoder_latent(latent),
+            prime_input=torch.Tensor([lang.start_index]).long(),
+            end_token=torch.Tensor([lang.stop_index]).long(),
+            generate_len=self.generate_len,
+            search=SamplingSearch(temperature=self.temperature),
+            seq_index_base=seq_index_base, early_exit=early_exit)
+
+    def get_smiles_from_latent(self, latent, remove_invalid=True):
+        """reinforce.py:149-211.  Returns (smiles, nums, valid_idxs)."""
+        lang = self.generator.smiles_language
+        mols_numerical = self.generator.generate(
+            self._decoder_latent(latent),
+            prime_input=torch.Tensor([lang.start_index]).long(),
+            end_token=torch.Tensor([lang.stop_index]).long(),
+            generate_len=self.generate_len,
+            search=SamplingSearch(temperature=self.temperature),
+        )
+        stops = torch.tensor(2 * [lang.stop_index])
+        smiles_num_tuple = [
+            (lang.token_indexes_to_smiles(mol_num.tolist()), torch.cat([mol_num.long(), stops]))
+            for mol_num in iter(mols_numerical)
+        ]
+        numericals = [sm[1] for sm in smiles_num_tuple]
+        smiles = [lang.selfies_to_smiles(sm[0]) for sm in smiles_num_tuple]
+        if self.is_valid is None:
+            raise RuntimeError('no validity check available: pass is_valid= (RDKit is not importable)')
+        ok = [bool(self.is_valid(s)) for s in smiles]
+        valid_idxs = [i for i in range(len(ok)) if ok[i]]
+        keep = [i for i in range(len(ok)) if not (remove_invalid and not ok[i])]
+        if self.logger is not None:
+            self.logger.info(f'{self.model_name}: SMILES validity: {100.0 * sum(ok) / max(1, len(ok)):.2f}%.')
+        return [smiles[i] for i in keep], [numericals[i] for i in keep], valid_idxs
+
+    # ------------------------------------------------------------------ learning
+    def _all_reduce_gradients(self, extra_params=()):
+        """One RCCL all-reduce (sum) of the flat gradient buffer."""
+        import torch.distributed as dist
+        params = [p for p in list(self.generator.decoder.parameters()) + list(extra_params) if p.grad is not None]
+        if not params:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+
+    def _global_count(self, n: int) -> int:
+        if self.process_group is None:
+            return n
+        import torch.distributed as dist
+        t = torch.tensor([float(n)], device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group)
+        return int(t.item())
+
+    def learn(self, latent_z, padded_nums, valid_idx, rewards, lrps: int = 1, n_valid_global=None):
+        """reinforce_omics.py:301-342 given sampled + scored molecules.
+
+        latent_z [1,B,latent_size] (autograd-connected to the encoder), padded_nums
+        [T_max,B_valid] (pad_sequence layout), valid_idx indices into B, rewards [B_valid].
+        Returns (mean_reward, loss_float)."""
+        dec = self.generator.decoder
+        dev = self.device
+        self.optimizer.zero_grad()
+        rewards_t = torch.as_tensor(np.asarray(rewards), dtype=torch.float32) if not torch.is_tensor(rewards) \
+            else rewards.to(torch.float32)
+        num_mols = padded_nums.shape[1]
+        dec._update_batch_size(num_mols)
+        idx = valid_idx if torch.is_tensor(valid_idx) else torch.as_tensor(valid_idx, dtype=torch.long)
+        hidden = dec.latent_to_hidden(
+            latent_z.to(dev).repeat(dec.n_layers, 1, lrps)[:, idx.to(dev), :])
+        n_glob = n_valid_global if n_valid_global is not None else self._global_count(num_mols)
+        loss, _ = ops.reinforce_loss(dec.weights(), padded_nums.to(dev), hidden, rewards_t.to(dev),
+                                     1.0 / max(1, n_glob))
+        summed_reward = torch.mean(rewards_t.float())
+        loss.backward()
+        enc_params = list(self.encoder.parameters()) if self.encoder is not None else []
+        if self.process_group is not None:
+            self._all_reduce_gradients(enc_params)
+        if self.grad_clipping is not None:
+            torch.nn.utils.clip_grad_norm_(list(dec.parameters()) + enc_params, self.grad_clipping)
+        self.optimizer.step()
+        return summed_reward, loss
+
+    def _policy_gradient(self, latent_z, target):
+        valid_smiles, valid_nums, valid_idx = self.get_smiles_from_latent(latent_z, remove_invalid=True)
+        if len(valid_nums) == 0:
+            if self.logger is not None:
+                self.logger.warning('no valid molecule in the batch: update skipped')
+            return torch.tensor(0.0), 0.0
+        rewards = self.get_reward(valid_smiles, target)
+        padded_nums = torch.nn.utils.rnn.pad_sequence(valid_nums)
+        lrps = 1
+        if self.encoder is not None and \
+                self.generator.decoder.latent_dim == 2 * getattr(self.encoder, 'latent_size', -1):
+            lrps = 2
+        r, loss = self.learn(latent_z, padded_nums, valid_idx, rewards, lrps)
+        return r, loss.item()
+
+    def get_reward(self, valid_smiles, target):
+        if self.reward_fn is None:
+            raise RuntimeError('no reward function: pass reward_fn= (drug evaluators are out of scope)')
+        return self.reward_fn(valid_smiles, target)
+
+    # ------------------------------------------------------------------ checkpoints (reinforce.py:261-285)
+    def load(self, generator_filepath=None, encoder_filepath=None, *args, **kwargs):
+        if generator_filepath is not None:
+            self.generator.load_model(self.weights_path.format(generator_filepath), *args, **kwargs)
+        if encoder_filepath is not None and self.encoder is not None:
+            self.encoder.load(self.weights_path.format(encoder_filepath), *args, **kwargs)
+
+    def save(self, generator_filepath=None, encoder_filepath=None, *args, **kwargs):
+        if generator_filepath is not None:
+            self.generator.save(self.weights_path.format(generator_filepath), *args, **kwargs)
+        if encoder_filepath is not None and self.encoder is not None and hasattr(self.encoder, 'save'):
+            self.encoder.save(self.weights_path.format(encoder_filepath), *args, **kwargs)
+
+
+class ReinforceOmic(Reinforce):
+    """reinforce_omics.py:13.  ``gep_df``: pandas frame with columns ``cell_line`` and
+    ``gene_expression`` (a Series of values per row), as at reinforce_omics.py:79-86."""
+
+    def __init__(self, generator, encoder, predictor, gep_df, params, model_name, logger, **kw):
+        self.predictor = predictor
+        if predictor is not None and hasattr(predictor, 'eval'):
+            predictor.eval()
+        self.gep_df = gep_df
+        super(ReinforceOmic, self).__init__(generator, encoder, params, model_name, logger, **kw)
+
+    def _gep_tensor(self, cell_line):
+        row = self.gep_df[self.gep_df['cell_line'] == cell_line].iloc[0]
+        return torch.unsqueeze(torch.Tensor(np.asarray(row.gene_expression.values, dtype=np.float32)), 0)
+
+    def encode_cell_line(self, cell_line=None, batch_size=128):
+        """reinforce_omics.py:75-95."""
+        gep_t = self._gep_tensor(cell_line).to(self.device)
+        cell_mu, cell_logvar = self.encoder(gep_t)
+        return torch.unsqueeze(
+            self.reparameterize(cell_mu.repeat(batch_size, 1), cell_logvar.repeat(batch_size, 1)), 0)
+
+    def policy_gradient(self, cell_line, epoch, batch_size=10):
+        """reinforce_omics.py:276-342.  Returns (mean reward, loss float)."""
+        latent_z = self.encode_cell_line(cell_line, batch_size)
+        return self._policy_gradient(latent_z, cell_line)
+
+
+class ReinforceProtein(Reinforce):
+    """reinforce_proteins.py.  ``protein_df``: frame indexed by protein name whose row holds
+    the encoder input vector (reinforce_proteins.py:85-131 with encoder_uses_sequence=False)."""
+
+    def __init__(self, generator, encoder, predictor, protein_df, params, model_name, logger, **kw):
+        self.predictor = predictor
+        if predictor is not None and hasattr(predictor, 'eval'):
+            predictor.eval()
+        self.protein_df = protein_df
+        super(ReinforceProtein, self).__init__(generator, encoder, params, model_name, logger, **kw)
+
+    def encode_protein(self, protein=None, batch_size=128):
+        """reinforce_proteins.py:60-83."""
+        if protein is None:
+            return torch.randn(1, batch_size, self.encoder.latent_size, device=self.device)
+        vec = np.asarray(self.protein_df.loc[protein].values, dtype=np.float32)
+        protein_tensor = torch.unsqueeze(torch.Tensor(vec), 0).to(self.device)
+        protein_mu, protein_logvar = self.encoder(protein_tensor)
+        return torch.unsqueeze(
+            self.reparameterize(protein_mu.repeat(batch_size, 1), protein_logvar.repeat(batch_size, 1)), 0)
+
+    def policy_gradient(self, protein, epoch, batch_size=10):
+        """reinforce_proteins.py:267-331."""
+        latent_z = self.encode_protein(protein, batch_size)
+        return self._policy_gradient(latent_z, protein)
+
+
+def pad_rows_on_device(tokens: torch.Tensor, lens: torch.Tensor, stop_index: int, t_max: Optional[int] = None):
+    """Device twin of reinforce.py:177-184 + pad_sequence (reinforce_omics.py:304): every row
+    becomes tokens[:len] + [stop, stop], zero-padded, seq-major [T_max, B]."""
+    B, N = tokens.shape
+    lens = lens.to(torch.int64)
+    if t_max is None:
+        t_max = int(lens.max().item()) + 2
+    pos = torch.arange(t_max, device=tokens.device).unsqueeze(1)  # [T,1]
+    body = torch.zeros(t_max, B, dtype=torch.int64, device=tokens.device)
+    n = min(N, t_max)
+    body[:n] = tokens.t()[:n]
+    L = lens.unsqueeze(0)
+    stop = torch.full_like(body, int(stop_index))
+    zero = torch.zeros_like(body)
+    return torch.where(pos < L, body, torch.where(pos < L + 2, stop, zero))

@@ -1,0 +1,175 @@
+"""HIP path vs CPU oracle, through the C ABI (needs an MI355X: run with -m gpu).
+
+Bars (BASELINE.json north_star): greedy tokens exact; teacher-forced log-probs and every
+REINFORCE gradient within 1e-4 relative (max-norm per tensor, against the fp64 oracle)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import parity as P
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def test_step_protocol(gpu):
+    P.check_step(P.TINY, 20)
+    P.check_step(dict(P.TINY, n_layers=2), 37)
+    P.check_step(P.CFG1, 64)
+
+
+def test_greedy_exact_tiny(gpu):
+    r = P.check_greedy(P.TINY, 20, 12)
+    assert r['mismatched_rows'] == 0
+
+
+def test_greedy_exact_cfg1(gpu):
+    """BASELINE.json configs[0] shape: hidden 256, vocab 60, batch 64, max_len 100."""
+    r = P.check_greedy(P.CFG1, 64, 100)
+    assert r['mismatched_rows'] == 0
+
+
+def test_greedy_two_layers(gpu):
+    r = P.check_greedy(dict(P.TINY, n_layers=2, rnn_cell_size=256), 33, 20)
+    assert r['mismatched_rows'] == 0
+
+
+@pytest.mark.parametrize('layers', [1, 2, 3])
+def test_train_parity_tiny(gpu, layers):
+    P.check_train(dict(P.TINY, n_layers=layers), B=20, T=9, tol=TOL)
+
+
+def test_train_parity_ragged_batch(gpu):
+    """B not a multiple of 16, single row, T=2 (one decoder step)."""
+    P.check_train(P.TINY, B=1, T=2, tol=TOL)
+    P.check_train(P.TINY, B=17, T=5, tol=TOL)
+    P.check_train(dict(P.TINY, pad_index=None), B=33, T=6, tol=TOL)
+
+
+def test_train_parity_cfg1(gpu):
+    P.check_train(P.CFG1, B=64, T=100, tol=TOL)
+
+
+def test_train_parity_cfg2_shape_small_batch(gpu):
+    """configs[1] model shape (hidden 512, stack 50x50) at a batch the oracle finishes in seconds."""
+    P.check_train(P.CFG2, B=48, T=40, tol=TOL)
+
+
+def test_train_parity_cfg4_shape_small_batch(gpu):
+    """configs[3] model shape (2 layers, hidden 1024)."""
+    P.check_train(P.CFG4, B=20, T=12, tol=TOL)
+
+
+def test_sampling_matches_oracle_draws(gpu):
+    r = P.check_sampling(P.TINY, 40, 16, temperature=0.8)
+    assert r['exact'] + r['boundary'] == 40 * 16
+    assert r['boundary'] <= 2
+    # chi-square of the token histogram against the summed oracle probabilities
+    exp, hist = r['expected'], r['hist']
+    m = exp > 5
+    chi2 = float(((hist[m] - exp[m]) ** 2 / exp[m]).sum())
+    assert chi2 < 3.0 * m.sum() + 30, chi2
+
+
+def test_sampling_is_sharding_invariant(gpu):
+    """Philox counters are keyed by the global sequence index: decoding a batch in two
+    shards gives the same tokens as decoding it whole."""
+    from paccmann_generator_amd import ops
+    _, pdec = P.make_pair(P.TINY)
+    torch.manual_seed(0)
+    latent = torch.randn(48, P.TINY['latent_dim'], device='cuda')
+    w = pdec.weights()
+    whole, wl = ops.decode(w, latent, P.START, P.STOP, 15, 0.9, seed=7, offset=3, early_exit=False)
+    a, al = ops.decode(w, latent[:20], P.START, P.STOP, 15, 0.9, seed=7, offset=3, seq_index_base=0,
+                       early_exit=False)
+    b, bl = ops.decode(w, latent[20:], P.START, P.STOP, 15, 0.9, seed=7, offset=3, seq_index_base=20,
+                       early_exit=False)
+    assert torch.equal(whole, torch.cat([a, b])) and torch.equal(wl, torch.cat([al, bl]))
+    again, _ = ops.decode(w, latent, P.START, P.STOP, 15, 0.9, seed=7, offset=3, early_exit=False)
+    assert torch.equal(whole, again)
+    other, _ = ops.decode(w, latent, P.START, P.STOP, 15, 0.9, seed=8, offset=3, early_exit=False)
+    assert not torch.equal(whole, other)
+
+
+def test_early_exit_only_changes_tokens_after_stop(gpu):
+    from paccmann_generator_amd import ops
+    _, pdec = P.make_pair(P.TINY)
+    with torch.no_grad():
+        pdec.output_layer.bias[P.STOP] += 3.0  # make stop likely so that whole groups finish
+    torch.manual_seed(0)
+    latent = torch.randn(64, P.TINY['latent_dim'], device='cuda')
+    w = pdec.weights()
+    full, fl = ops.decode(w, latent, P.START, P.STOP, 40, 1.0, seed=1, early_exit=False)
+    cut, cl = ops.decode(w, latent, P.START, P.STOP, 40, 1.0, seed=1, early_exit=True)
+    assert torch.equal(fl, cl)
+    assert int(fl.max()) < 40
+    for r in range(64):
+        n = int(fl[r])
+        assert torch.equal(full[r, :n + 1], cut[r, :n + 1])
+
+
+def test_gradient_accumulate_and_h0_grad_flow(gpu):
+    """grad_h0 reaches latent_to_hidden through torch autograd (reinforce_omics.py:313, :335)."""
+    from paccmann_generator_amd import ops
+    odec, pdec = P.make_pair(P.TINY)
+    B, T = 12, 7
+    tokens = P.synthetic_tokens(T, B, P.TINY['vocab_size'])
+    torch.manual_seed(1)
+    latent = torch.randn(1, B, P.TINY['latent_dim'])
+    reward = torch.rand(B)
+    from oracle import reinforce_loop as RL
+    h_o = RL.initial_hidden(odec, latent, list(range(B)), 1)
+    RL.reinforce_loss(odec, tokens, h_o, reward[:, None]).backward()
+    h_p = pdec.latent_to_hidden(latent.cuda().repeat(1, 1, 1))
+    loss, _ = ops.reinforce_loss(pdec.weights(), tokens.cuda(), h_p, reward.cuda(), 1.0 / B)
+    loss.backward()
+    for n in ('weight', 'bias'):
+        go = getattr(odec.latent_to_hidden, n).grad
+        gp = getattr(pdec.latent_to_hidden, n).grad.cpu()
+        assert P.rel_err(gp, go) < TOL
+
+
+def test_linearity_in_reward_full_size_property(gpu):
+    """Size-independent property at a large batch: gradients are linear in the reward
+    (g(a*R1 + b*R2) = a*g(R1) + b*g(R2)) and rows with zero reward contribute nothing."""
+    from paccmann_generator_amd import ops
+    _, pdec = P.make_pair(P.CFG1)
+    B, T = 512, 40
+    tokens = P.synthetic_tokens(T, B, 60).cuda()
+    torch.manual_seed(0)
+    h0 = torch.tanh(torch.randn(1, B, 256, device='cuda'))
+    R1, R2 = torch.rand(B, device='cuda'), torch.rand(B, device='cuda')
+
+    def grads(R):
+        for p in pdec.parameters():
+            p.grad = None
+        loss, _ = ops.reinforce_loss(pdec.weights(), tokens, h0, R, 1.0 / B)
+        loss.backward()
+        return torch.cat([p.grad.reshape(-1) for p in pdec.parameters() if p.grad is not None]), loss.item()
+
+    g1, l1 = grads(R1)
+    g2, l2 = grads(R2)
+    g3, l3 = grads(0.3 * R1 + 1.7 * R2)
+    ref = 0.3 * g1 + 1.7 * g2
+    assert float((g3 - ref).abs().max() / ref.abs().max()) < 1e-4
+    assert abs(l3 - (0.3 * l1 + 1.7 * l2)) < 1e-4 * abs(l3)
+    Rm = R1.clone()
+    Rm[B // 2:] = 0
+    gm, _ = grads(Rm)
+    for p in pdec.parameters():
+        p.grad = None
+    loss, _ = ops.reinforce_loss(pdec.weights(), tokens[:, :B // 2].contiguous(), h0[:, :B // 2].contiguous(),
+                                 R1[:B // 2].contiguous(), 1.0 / B)
+    loss.backward()
+    gh = torch.cat([p.grad.reshape(-1) for p in pdec.parameters() if p.grad is not None])
+    assert float((gm - gh).abs().max() / gh.abs().max()) < 1e-4
+
+
+def test_shape_errors_are_reported(gpu):
+    from paccmann_generator_amd import _ffi
+    s = _ffi.make_shape(8, 4, 100, 16, 10, 7, 23, 1, 32, 0)
+    assert _ffi.lib.pmg_check_shape(s, _ffi.PMG_MODE_TRAIN) < 0
+    with pytest.raises(_ffi.PmgError):
+        _ffi.workspace_bytes(s, _ffi.PMG_MODE_TRAIN)
+    with pytest.raises(_ffi.PmgError):
+        _ffi._ptr(torch.zeros(3))  # CPU tensor: no CPU path
