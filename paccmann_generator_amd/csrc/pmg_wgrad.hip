@@ -21,7 +21,6 @@
 #include <string.h>
 
 #define WG_TM 128
-#define WG_TN 128
 #define WG_THREADS 256
 #define WG_MAXJOBS (2 + 2 * PMG_MAX_LAYERS + 1)
 
@@ -33,55 +32,71 @@ struct WJob {
   int b_rows;       // rows of one B slab
   int b_pshift;     // time shift of the B slabs
   int rows, cols;   // logical C size
+  int tn;           // column tile: 128 (wide kernel) or 64 (narrow kernel)
   int row_tiles, col_tiles;
-  int tile0;        // first global tile index
+  int tile0;        // first tile index within its kernel variant's grid
   int rs0;          // offset of this job's row sums in the row-sum vector
   int P;            // time slabs
   size_t c_off;     // offset of the dense C in the accumulator region
+  size_t pt_off;    // offset of this job's first partial tile within one split's partial block
 };
 
 struct WgradArgs {
-  int njobs, total_tiles, total_rs, S;
+  int njobs, total_rs, S;
   int G, B, H;
+  int tiles_wide, tiles_narrow;
+  size_t split_stride;  // floats of partial tiles per split
   const int64_t* tokens;
   WJob jobs[WG_MAXJOBS];
-  float* partial;   // [S][total_tiles][128*128]
+  float* partial;     // [S][split_stride]
   float* rs_partial;  // [S][total_rs]
-  float* dense;     // accumulators
+  float* dense;       // accumulators
 };
 
 namespace {
 
+// Wave tile = (16*MI) x (16*NJ); workgroup = WR x WC waves; TM = 16*MI*WR = 128.
+// The hot loop is branch-free: out-of-range row/column fragments are clamped to row 0 of
+// the slab and their (garbage) results are simply never read back.
+template <int MI, int NJ, int WR, int WC>
 __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArgs a) {
+  constexpr int TN = 16 * NJ * WC;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int n16 = lane & 15, q = lane >> 4;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int s = blockIdx.x / a.total_tiles;
-  const int t = blockIdx.x - s * a.total_tiles;
-  int ji = 0;
-  for (int k = 1; k < a.njobs; ++k)
-    if (t >= a.jobs[k].tile0) ji = k;
+  const int wr = wave / WC, wc = wave - wr * WC;
+  const int ntiles = (TN == 128) ? a.tiles_wide : a.tiles_narrow;
+  // XCD-aware remap: blocks b and b+8 share an XCD; give each XCD a contiguous run of
+  // virtual ids so that the tiles of one split (same slabs) meet in one L2.
+  const int nblk = gridDim.x;  // multiple of 8
+  const int v = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+  if (v >= ntiles * a.S) return;
+  const int s = v / ntiles;
+  const int t = v - s * ntiles;
+  int ji = -1;
+  for (int k = 0; k < a.njobs; ++k)
+    if (a.jobs[k].tn == TN && t >= a.jobs[k].tile0) ji = k;
   const WJob& jb = a.jobs[ji];
   const int tl = t - jb.tile0;
   const int rt = tl / jb.col_tiles, ct = tl - rt * jb.col_tiles;
-  const int r0 = rt * WG_TM + wr * 64;
-  const int c0 = ct * WG_TN + wc * 64;
+  const int r0 = rt * WG_TM + wr * 16 * MI;
+  const int c0 = ct * TN + wc * 16 * NJ;
   const int H = a.H, G = a.G;
 
-  bool va[4], vb[4];
-  size_t aoff[4], boff[4];
+  size_t aoff[MI], boff[NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = r0 + 16 * i;
-    va[i] = r < jb.rows;
-    int rr = r + n16;
+  for (int i = 0; i < MI; ++i) {
+    int rr = r0 + 16 * i + n16;
+    if (r0 + 16 * i >= jb.rows) rr = n16;  // clamp: result rows are ignored
     if (jb.skip_mid && rr >= 2 * H) rr += H;
     aoff[i] = (size_t)rr * 16 + 4 * q;
-    const int c = c0 + 16 * i;
-    vb[i] = c < jb.cols;
-    boff[i] = (size_t)(c + n16) * 16 + 4 * q;
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    int cc = c0 + 16 * j + n16;
+    if (c0 + 16 * j >= jb.cols) cc = n16;
+    boff[j] = (size_t)cc * 16 + 4 * q;
   }
   const bool onehot = (jb.B == nullptr);
 
@@ -90,24 +105,29 @@ __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArg
   const int sl0 = s * per;
   const int sl1 = (sl0 + per < nslab) ? sl0 + per : nslab;
 
-  f32x4 acc[4][4];
+  f32x4 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float rsum[4] = {0.f, 0.f, 0.f, 0.f};
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float rsum[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) rsum[i] = 0.f;
 
-  auto load_a = [&](int sl, float4 (&fa)[4]) {
-    const float* As = jb.A + (size_t)sl * jb.a_rows * 16;
+  const float* Ab = jb.A;
+  const float* Bb = onehot ? nullptr : jb.B + (size_t)jb.b_pshift * G * jb.b_rows * 16;
+  const size_t astr = (size_t)jb.a_rows * 16, bstr = (size_t)jb.b_rows * 16;
+
+  auto load_a = [&](int sl, float4 (&fa)[MI]) {
+    const float* As = Ab + (size_t)sl * astr;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa[i] = va[i] ? *reinterpret_cast<const float4*>(As + aoff[i]) : zero;
+    for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const float4*>(As + aoff[i]);
   };
-  auto load_b = [&](int sl, float4 (&fb)[4]) {
+  auto load_b = [&](int sl, float4 (&fb)[NJ]) {
     if (!onehot) {
-      const float* Bs = jb.B + ((size_t)sl + (size_t)jb.b_pshift * G) * jb.b_rows * 16;
+      const float* Bs = Bb + (size_t)sl * bstr;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = vb[j] ? *reinterpret_cast<const float4*>(Bs + boff[j]) : zero;
+      for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const float4*>(Bs + boff[j]);
     } else {
       const int p = sl / G, g = sl - p * G;
       int tk[4];
@@ -117,7 +137,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArg
         tk[c] = (row < a.B) ? (int)a.tokens[(size_t)p * a.B + row] : -1;
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int col = c0 + 16 * j + n16;
         fb[j] = make_float4(tk[0] == col ? 1.f : 0.f, tk[1] == col ? 1.f : 0.f, tk[2] == col ? 1.f : 0.f,
                             tk[3] == col ? 1.f : 0.f);
@@ -126,47 +146,50 @@ __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArg
   };
 
   if (sl0 < sl1) {
-    float4 fa[4], fb[4];
+    float4 fa[MI], fb[NJ];
     load_a(sl0, fa);
     load_b(sl0, fb);
+#pragma unroll 1
     for (int sl = sl0; sl < sl1; ++sl) {
-      float4 na[4], nb[4];
+      float4 na[MI], nb[NJ];
       const int sn = (sl + 1 < sl1) ? sl + 1 : sl;
       load_a(sn, na);
       load_b(sn, nb);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rsum[i] += (fa[i].x + fa[i].y) + (fa[i].z + fa[i].w);
+      for (int i = 0; i < MI; ++i) rsum[i] += (fa[i].x + fa[i].y) + (fa[i].z + fa[i].w);
 #define WG_STEP(C)                                                                                   \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)        \
-      if (va[i] && vb[j]) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].C, fb[j].C, acc[i][j], 0, 0, 0);
+  _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)      \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].C, fb[j].C, acc[i][j], 0, 0, 0);
       WG_STEP(x) WG_STEP(y) WG_STEP(z) WG_STEP(w)
 #undef WG_STEP
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { fa[i] = na[i]; fb[i] = nb[i]; }
+      for (int i = 0; i < MI; ++i) fa[i] = na[i];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) fb[j] = nb[j];
     }
   }
 
-  // partial tile: [128][128], element (row_local, col_local)
-  float* pt = a.partial + ((size_t)s * a.total_tiles + t) * (WG_TM * WG_TN);
+  // partial tile: [128][TN], element (row_local, col_local)
+  float* pt = a.partial + (size_t)s * a.split_stride + jb.pt_off + (size_t)tl * (WG_TM * TN);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int rl = wr * 64 + 16 * i + 4 * q + rg;
-        const int cl = wc * 64 + 16 * j + n16;
-        pt[rl * WG_TN + cl] = acc[i][j][rg];
+        const int rl = wr * 16 * MI + 16 * i + 4 * q + rg;
+        const int cl = wc * 16 * NJ + 16 * j + n16;
+        pt[rl * TN + cl] = acc[i][j][rg];
       }
   // row sums (bias gradients): only the first column tile's wc==0 waves own them
   if (ct == 0 && wc == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float v = rsum[i];
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
+    for (int i = 0; i < MI; ++i) {
+      float v2 = rsum[i];
+      v2 += __shfl_xor(v2, 16);
+      v2 += __shfl_xor(v2, 32);
       const int r = r0 + 16 * i + n16;
-      if (q == 0 && r < jb.rows) a.rs_partial[(size_t)s * a.total_rs + jb.rs0 + r] = v;
+      if (q == 0 && r < jb.rows) a.rs_partial[(size_t)s * a.total_rs + jb.rs0 + r] = v2;
     }
   }
 }
@@ -188,16 +211,16 @@ __global__ void pmg_wgrad_reduce_kernel(const WgradArgs a) {
       }
       const WJob& jb = a.jobs[ji];
       const int r = (int)(rem / jb.cols), c = (int)(rem % jb.cols);
-      const int t = jb.tile0 + (r / WG_TM) * jb.col_tiles + (c / WG_TN);
-      const size_t e = (size_t)(r % WG_TM) * WG_TN + (c % WG_TN);
+      const int tl = (r / WG_TM) * jb.col_tiles + (c / jb.tn);
+      const size_t e = jb.pt_off + (size_t)tl * (WG_TM * jb.tn) + (size_t)(r % WG_TM) * jb.tn + (c % jb.tn);
       float sum = 0.0f;
-      for (int s = 0; s < a.S; ++s) sum += a.partial[((size_t)s * a.total_tiles + t) * (WG_TM * WG_TN) + e];
+      for (int s = 0; s < a.S; ++s) sum += a.partial[(size_t)s * a.split_stride + e];
       a.dense[jb.c_off + rem] = sum;
     } else {
       const size_t r = idx - total;
       float sum = 0.0f;
       for (int s = 0; s < a.S; ++s) sum += a.rs_partial[(size_t)s * a.total_rs + r];
-      a.dense[a.jobs[0].c_off + total + r] = sum;  // row sums live right after the dense matrices
+      a.dense[total + r] = sum;  // row sums live right after the dense matrices
     }
   }
 }
@@ -317,16 +340,19 @@ void build_plan(const PmgDims& d, JobPlan* P) {
   WgradArgs& w = P->w;
   FinArgs& f = P->f;
   const int H = d.H, N = d.T - 1;
-  int nj = 0, tile = 0, rs = 0;
-  size_t coff = 0;
+  int nj = 0, tile_w = 0, tile_n = 0, rs = 0;
+  size_t coff = 0, ptoff = 0;
   auto add = [&](int rows, int cols, int a_rows, int skip_mid, int b_rows, int b_pshift, int Psl) -> WJob& {
     WJob& j = w.jobs[nj++];
     j.rows = rows; j.cols = cols; j.a_rows = a_rows; j.skip_mid = skip_mid; j.b_rows = b_rows;
     j.b_pshift = b_pshift; j.P = Psl;
-    j.row_tiles = pmg_ceil_div(rows, WG_TM); j.col_tiles = pmg_ceil_div(cols, WG_TN);
-    j.tile0 = tile; tile += j.row_tiles * j.col_tiles;
+    j.tn = (cols <= 64) ? 64 : 128;
+    j.row_tiles = pmg_ceil_div(rows, WG_TM); j.col_tiles = pmg_ceil_div(cols, j.tn);
+    const int nt = j.row_tiles * j.col_tiles;
+    if (j.tn == 128) { j.tile0 = tile_w; tile_w += nt; } else { j.tile0 = tile_n; tile_n += nt; }
     j.rs0 = rs; rs += rows;
     j.c_off = coff; coff += (size_t)rows * cols;
+    j.pt_off = ptoff; ptoff += (size_t)nt * WG_TM * j.tn;
     return j;
   };
   // job order is fixed; pointers are filled by the caller
@@ -337,14 +363,15 @@ void build_plan(const PmgDims& d, JobPlan* P) {
   }
   { WJob& j = add(3 * H, d.VP, 4 * H, 0, 0, 0, N); f.c_tab = j.c_off; }
   { WJob& j = add(d.NXT * 16, H, d.NXT * 16, 0, H, 0, N + 1); f.c_x = j.c_off; f.rs_x = j.rs0; }
-  w.njobs = nj; w.total_tiles = tile; w.total_rs = rs;
-  w.S = choose_splits(d, tile);
+  w.njobs = nj; w.tiles_wide = tile_w; w.tiles_narrow = tile_n; w.total_rs = rs;
+  w.S = choose_splits(d, tile_w + tile_n);
+  w.split_stride = ptoff;
   w.G = d.G; w.B = d.B; w.H = H;
   // row sums are stored right behind the dense matrices
   for (int l = 0; l < d.L; ++l) { f.rs_hh[l] += coff; f.rs_gi[l] += coff; }
   f.rs_x += coff;
   P->dense_floats = coff + rs;
-  P->partial_floats = (size_t)w.S * tile * (WG_TM * WG_TN);
+  P->partial_floats = (size_t)w.S * ptoff;
   P->rs_partial_floats = (size_t)w.S * rs;
 }
 
@@ -382,9 +409,19 @@ hipError_t pmg_run_wgrad(const PmgDims& d, const PmgLayout& lay, float* ws, cons
   w.jobs[k].A = ws + lay.DG[0]; w.jobs[k].B = nullptr; ++k;
   w.jobs[k].A = ws + lay.DX; w.jobs[k].B = ws + lay.HH[d.L - 1]; ++k;
 
-  hipLaunchKernelGGL(pmg_wgrad_kernel, dim3(w.total_tiles * w.S), dim3(WG_THREADS), 0, st, w);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  hipError_t e = hipSuccess;
+  if (w.tiles_wide > 0) {
+    const int nb = ((w.tiles_wide * w.S + 7) / 8) * 8;
+    hipLaunchKernelGGL((pmg_wgrad_kernel<4, 4, 2, 2>), dim3(nb), dim3(WG_THREADS), 0, st, w);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  if (w.tiles_narrow > 0) {
+    const int nb = ((w.tiles_narrow * w.S + 7) / 8) * 8;
+    hipLaunchKernelGGL((pmg_wgrad_kernel<2, 4, 4, 1>), dim3(nb), dim3(WG_THREADS), 0, st, w);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
   {
     size_t total = P.dense_floats;
     int blocks = (int)((total + 255) / 256);
