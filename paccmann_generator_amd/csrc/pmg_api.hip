@@ -2,6 +2,13 @@
 // packing and kernel sequencing.  Allocates nothing, never synchronises.
 #include "pmg_kernels.h"
 #include <string.h>
+#include <stdlib.h>
+
+// PMG_DEBUG=<hex>: ablation bits for timing experiments (skip a phase of the kernels).
+static int debug_bits() {
+  const char* e = getenv("PMG_DEBUG");
+  return e ? (int)strtol(e, nullptr, 16) : 0;
+}
 
 // implemented in pmg_wgrad.hip
 struct WgradArgs;
@@ -28,6 +35,7 @@ static void make_layout(const PmgDims& d, int mode, PmgLayout* L) {
   }
   if (mode == PMG_MODE_DECODE) {
     L->H0 = take((size_t)H * d.Z);  // packed latent_to_hidden
+    L->pack_end = off;
     L->SB = take(2 * G * (size_t)d.SW);
   } else {
     L->WXt = take((size_t)d.NXT * 16 * H);
@@ -35,6 +43,7 @@ static void make_layout(const PmgDims& d, int mode, PmgLayout* L) {
       L->WHHt[l] = take(3 * H * H);
       L->WIHt[l] = take(l == 0 ? (size_t)PMG_KS * 3 * H : 3 * H * H);
     }
+    L->pack_end = off;
     L->SB = take(T * G * (size_t)d.SW);
     for (int l = 0; l < d.L; ++l) {
       L->HH[l] = take(T * G * H * 16);
@@ -164,14 +173,17 @@ static int check_weights(const pmg_shape* s, const pmg_weights* w, bool need_l2h
 
 static void fill_fwd_common(FwdArgs* a, const PmgDims& d, const PmgLayout& lay, float* base) {
   memset(a, 0, sizeof(*a));
+  a->dbg = debug_bits();
   a->B = d.B; a->G = d.G; a->H = d.H; a->W = d.W; a->D = d.D; a->V = d.V; a->L = d.L; a->Z = d.Z;
   a->NX = d.NX; a->NXT = d.NXT; a->XP = d.XP; a->HP = d.HP; a->KGH = d.KGH; a->VP = d.VP; a->SW = d.SW;
-  a->WXp = reinterpret_cast<const float4*>(base + lay.WXp);
+  a->wbase = base;
+  a->wbytes = (unsigned)(lay.pack_end * sizeof(float));
+  a->oWX = (unsigned)(lay.WXp * 4);
   a->BX = base + lay.BX;
   a->GTAB = base + lay.GTAB;
   for (int l = 0; l < d.L; ++l) {
-    a->WHHp[l] = reinterpret_cast<const float4*>(base + lay.WHHp[l]);
-    a->WIHp[l] = reinterpret_cast<const float4*>(base + lay.WIHp[l]);
+    a->oWHH[l] = (unsigned)(lay.WHHp[l] * 4);
+    a->oWIH[l] = (unsigned)(lay.WIHp[l] * 4);
     a->BG[l] = base + lay.BG[l];
   }
   a->SB = base + lay.SB;
@@ -199,7 +211,7 @@ extern "C" int pmg_decode(const pmg_shape* s, const pmg_weights* w, const float*
   a.N = gen_len;
   a.start_tok = start_tok; a.stop_tok = stop_tok; a.temperature = temperature; a.flags = flags;
   a.seed = philox_seed; a.offset = philox_offset; a.seq_base = seq_index_base;
-  a.L2Hp = reinterpret_cast<const float4*>(base + lay.H0);
+  a.oL2H = (unsigned)(lay.H0 * 4);
   a.b_l2h = w->b_l2h;
   a.latent = latent;
   a.tok_out = tokens_out; a.len_out = len_out;
@@ -282,11 +294,13 @@ extern "C" int pmg_reinforce_bwd(const pmg_shape* s, const pmg_weights* w, const
   memset(&a, 0, sizeof(a));
   a.B = d.B; a.G = d.G; a.N = d.T - 1; a.H = d.H; a.W = d.W; a.D = d.D; a.V = d.V; a.L = d.L;
   a.NX = d.NX; a.NXT = d.NXT; a.XP = d.XP; a.KGH = d.KGH; a.VP = d.VP; a.SW = d.SW; a.UPW = d.UPW;
-  a.scale = scale; a.tokens = tokens; a.reward = reward;
-  a.WXt = reinterpret_cast<const float4*>(base + lay.WXt);
+  a.scale = scale; a.tokens = tokens; a.reward = reward; a.dbg = debug_bits();
+  a.wbase = base;
+  a.wbytes = (unsigned)(lay.pack_end * sizeof(float));
+  a.oWXt = (unsigned)(lay.WXt * 4);
   for (int l = 0; l < d.L; ++l) {
-    a.WHHt[l] = reinterpret_cast<const float4*>(base + lay.WHHt[l]);
-    a.WIHt[l] = reinterpret_cast<const float4*>(base + lay.WIHt[l]);
+    a.oWHHt[l] = (unsigned)(lay.WHHt[l] * 4);
+    a.oWIHt[l] = (unsigned)(lay.WIHt[l] * 4);
     a.HH[l] = base + lay.HH[l]; a.GT[l] = base + lay.GT[l]; a.DG[l] = base + lay.DG[l];
   }
   a.SB = base + lay.SB; a.CT = base + lay.CT; a.PV = base + lay.PV; a.PR = base + lay.PR;

@@ -27,41 +27,57 @@ __device__ __forceinline__ void st4(float* p, const f32x4 v) {
 
 // acc[t] += Wt[tile t][groups of this chunk] * chunk columns.  24 reduction groups:
 // 8 per piece; pcN = LDS column block (of 128) holding piece N of this product.
+// Weights through the buffer resource (voff = lane*16, soff = first tile, first group of the
+// chunk, ts = bytes per tile).  Two register sets + sched_barriers keep the next group's
+// loads in flight under the current group's MFMAs.
 template <int NT>
-__device__ __forceinline__ void gemm_chunk(f32x4 (&acc)[NT], const float4* __restrict__ wp, const size_t ts,
-                                           const float* xb, const int pc0, const int pc1, const int pc2) {
-  float4 wc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) wc[t] = wp[t * ts];
-#pragma unroll 1
-  for (int rg = 0; rg < 24; ++rg) {
-    const int piece = rg >> 3;
-    const int pc = (piece == 0) ? pc0 : (piece == 1) ? pc1 : pc2;
-    const float4 x = *reinterpret_cast<const float4*>(xb + pc * PMG_CHUNK + (rg & 7) * 16);
-    const int rn = (rg + 1 < 24) ? rg + 1 : rg;
-    float4 wn[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) wn[t] = wp[t * ts + (size_t)rn * 64];
-#define PMG_STEP(C)                                                                      \
+__device__ __forceinline__ void gemm_chunk(f32x4 (&acc)[NT], const __amdgpu_buffer_rsrc_t rs, const unsigned voff,
+                                           const unsigned soff, const unsigned ts, const float* xb, const int pc0,
+                                           const int pc1, const int pc2) {
+  float4 wa[NT], wb[NT];
+#define PMG_LOAD(dst, rgi) \
+  _Pragma("unroll") for (int t = 0; t < NT; ++t) dst[t] = pmg_bload(rs, voff, soff + t * ts + (unsigned)(rgi) * 1024u);
+#define PMG_STEP(wc, C)                                                                  \
   _Pragma("unroll") for (int t = 0; t < NT; ++t)                                         \
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[t].C, x.C, acc[t], 0, 0, 0);
-    PMG_STEP(x) PMG_STEP(y) PMG_STEP(z) PMG_STEP(w)
-#undef PMG_STEP
-#pragma unroll
-    for (int t = 0; t < NT; ++t) wc[t] = wn[t];
+  PMG_LOAD(wa, 0)
+#pragma unroll 1
+  for (int rg = 0; rg < 24; rg += 2) {
+    const int piece = rg >> 3;
+    const int pc = (piece == 0) ? pc0 : (piece == 1) ? pc1 : pc2;
+    const float* xp = xb + pc * PMG_CHUNK + (rg & 7) * 16;
+    PMG_LOAD(wb, rg + 1)
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const float4 x = *reinterpret_cast<const float4*>(xp);
+      PMG_STEP(wa, x) PMG_STEP(wa, y) PMG_STEP(wa, z) PMG_STEP(wa, w)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int rn = (rg + 2 < 24) ? rg + 2 : rg;
+      PMG_LOAD(wa, rn)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const float4 x = *reinterpret_cast<const float4*>(xp + 16);
+      PMG_STEP(wb, x) PMG_STEP(wb, y) PMG_STEP(wb, z) PMG_STEP(wb, w)
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
+#undef PMG_STEP
+#undef PMG_LOAD
 }
 
 // acc[t] += Wt[tile t][0..KG) * x[b][0..16*KG)   (plain contiguous reduction)
 template <int NT>
-__device__ __forceinline__ void gemm_lin(f32x4 (&acc)[NT], const float4* __restrict__ wp, const size_t ts,
-                                         const float* xrow, const int KG) {
-#pragma unroll 1
+__device__ __forceinline__ void gemm_lin(f32x4 (&acc)[NT], const __amdgpu_buffer_rsrc_t rs, const unsigned voff,
+                                         const unsigned soff, const unsigned ts, const float* xrow, const int KG) {
+#pragma unroll 2
   for (int kg = 0; kg < KG; ++kg) {
     const float4 x = *reinterpret_cast<const float4*>(xrow + 16 * kg);
     float4 wc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) wc[t] = wp[t * ts + (size_t)kg * 64];
+    for (int t = 0; t < NT; ++t) wc[t] = pmg_bload(rs, voff, soff + t * ts + (unsigned)kg * 1024u);
 #define PMG_STEP(C)                                                                      \
   _Pragma("unroll") for (int t = 0; t < NT; ++t)                                         \
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[t].C, x.C, acc[t], 0, 0, 0);
@@ -75,6 +91,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int H = a.H, XP = a.XP, W = a.W, D = a.D, V = a.V, L = a.L, B = a.B, G = a.G, N = a.N;
   const int UT = H / 16, NXT = a.NXT;
+  const int dbg = a.dbg;
   float* cb = reinterpret_cast<float*>(smem);   // [2][16][PMG_CP]
   float* dxl = cb + 2 * 16 * PMG_CP;            // [16][XP]   dctrl | dpush | dlogits
   float* dtl = dxl + 16 * XP;                   // [16][PMG_XTP] dtop
@@ -87,7 +104,9 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
   const int b = lane & 15, q = lane >> 4;
   const int g = blockIdx.x;
   const int row0 = g * PMG_ROWS;
-  const size_t KG3 = (size_t)3 * H / 16;  // reduction groups of the gate products
+  const unsigned KG3 = 3u * (unsigned)H / 16u;  // reduction groups of the gate products
+  const __amdgpu_buffer_rsrc_t wrs = pmg_rsrc(a.wbase, a.wbytes);
+  const unsigned voff = (unsigned)lane * 16u;
 
   float* dhc = a.DHC + (size_t)g * L * H * 16;
   // zero the carry (own elements only: each lane re-reads exactly what it wrote)
@@ -153,6 +172,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
           float* cbw = cb + (size_t)par * 16 * PMG_CP + b * PMG_CP + 16 * wave + 4 * q;
           st4(cbw, dr_pre); st4(cbw + PMG_CHUNK, dz_pre); st4(cbw + 2 * PMG_CHUNK, dn_pre);
           st4(cbw + 3 * PMG_CHUNK, dghn);
+          if (!(dbg & 0x1000))
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             dg_base[((size_t)(0 * H + j0 + j)) * 16 + b] = dr_pre[j];
@@ -164,15 +184,15 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
           // ---- products over this chunk's 3*128 reduction rows
           const float* xb = cb + (size_t)par * 16 * PMG_CP + b * PMG_CP + 4 * q;
           {
-            const float4* wp = a.WHHt[l] + ((size_t)(wave * UPW) * KG3 + (size_t)c * 24) * 64 + lane;
-            gemm_chunk<UPW>(acc_hh, wp, KG3 * 64, xb, 0, 1, 3);
+            const unsigned so = a.oWHHt[l] + ((unsigned)(wave * UPW) * KG3 + (unsigned)c * 24u) * 1024u;
+            if (!(dbg & 0x400)) gemm_chunk<UPW>(acc_hh, wrs, voff, so, KG3 * 1024u, xb, 0, 1, 3);
           }
           if (l > 0) {
-            const float4* wp = a.WIHt[l] + ((size_t)(wave * UPW) * KG3 + (size_t)c * 24) * 64 + lane;
-            gemm_chunk<UPW>(acc_dx, wp, KG3 * 64, xb, 0, 1, 2);
+            const unsigned so = a.oWIHt[l] + ((unsigned)(wave * UPW) * KG3 + (unsigned)c * 24u) * 1024u;
+            gemm_chunk<UPW>(acc_dx, wrs, voff, so, KG3 * 1024u, xb, 0, 1, 2);
           } else if (wave < PMG_KS / 16) {
-            const float4* wp = a.WIHt[0] + ((size_t)wave * KG3 + (size_t)c * 24) * 64 + lane;
-            gemm_chunk<1>(acc_top, wp, KG3 * 64, xb, 0, 1, 2);
+            const unsigned so = a.oWIHt[0] + ((unsigned)wave * KG3 + (unsigned)c * 24u) * 1024u;
+            if (!(dbg & 0x800)) gemm_chunk<1>(acc_top, wrs, voff, so, KG3 * 1024u, xb, 0, 1, 2);
           }
           par ^= 1;
         }
@@ -187,7 +207,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
     }
 
     // ------------------------------------------------------------ stack backward
-    if (!virt) {
+    if (!virt && !(dbg & 0x100)) {
       const int ncol = W * 4;
       int dsplit = PMG_THREADS / ncol;
       if (dsplit < 1) dsplit = 1;
@@ -303,8 +323,8 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
       f32x4 acc[UPW];
 #pragma unroll
       for (int u = 0; u < UPW; ++u) acc[u] = ld4(dhc + ((size_t)((L - 1) * UT + wave * UPW + u)) * 256 + lane * 4);
-      const float4* wp = a.WXt + ((size_t)(wave * UPW) * NXT) * 64 + lane;
-      gemm_lin<UPW>(acc, wp, (size_t)NXT * 64, dxl + b * XP + 4 * q, NXT);
+      const unsigned so = a.oWXt + (unsigned)(wave * UPW) * (unsigned)NXT * 1024u;
+      if (!(dbg & 0x200)) gemm_lin<UPW>(acc, wrs, voff, so, (unsigned)NXT * 1024u, dxl + b * XP + 4 * q, NXT);
 #pragma unroll
       for (int u = 0; u < UPW; ++u) st4(dhc + ((size_t)((L - 1) * UT + wave * UPW + u)) * 256 + lane * 4, acc[u]);
     }

@@ -93,6 +93,7 @@ struct PmgLayout {
   size_t DHC;                 // [G][L][H*16] hidden-gradient carry
   size_t WG;                  // weight-gradient accumulators (packed "natural" matrices)
   size_t WGP;                 // split-K partials
+  size_t pack_end;            // end of the packed-weight region (covered by one buffer resource)
   size_t total;               // floats
 };
 
@@ -105,6 +106,18 @@ __device__ __forceinline__ f32x4 mfma4(f32x4 acc, const float4 w, const float4 x
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x.z, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x.w, acc, 0, 0, 0);
   return acc;
+}
+
+// 16-byte load through a buffer resource: SGPR descriptor + one 32-bit per-lane offset
+// (voff) + a wave-uniform byte offset (soff).  No 64-bit address VGPRs; out-of-range reads
+// return 0.
+typedef unsigned int pmg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 pmg_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const pmg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pmg_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
 
 __device__ __forceinline__ float pmg_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

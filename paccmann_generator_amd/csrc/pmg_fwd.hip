@@ -26,57 +26,74 @@ __device__ __forceinline__ void st4(float* p, const f32x4 v) {
 }
 
 // acc{r,z,t}[u0..u0+TPP) += W[tiles 3*u0 ..] * X   over KG groups of 16 columns.
-// wp points at (first tile, kg 0, this lane); xrow at this lane's LDS row + 4*(lane>>4).
+// Weights come through the buffer resource `rs`: voff = lane*16, soff = byte offset of
+// (first tile, group 0); xrow = this lane's LDS row + 4*(lane>>4).
+// Two register sets (wa, wb), loop unrolled by two: the loads of group kg+1 are in flight
+// while the MFMAs of group kg run (the sched_barriers keep hipcc from re-fusing load and
+// use, which it otherwise does).  KG is even.
 template <int UPW, int TPP>
 __device__ __forceinline__ void gemm3_pass(f32x4 (&ar)[UPW], f32x4 (&az)[UPW], f32x4 (&at)[UPW], const int u0,
-                                           const float4* __restrict__ wp, const int KG, const float* xrow) {
+                                           const __amdgpu_buffer_rsrc_t rs, const unsigned voff,
+                                           const unsigned soff, const int KG, const float* xrow) {
   constexpr int NT = 3 * TPP;
-  const size_t ts = (size_t)KG * 64;
-  float4 wc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) wc[t] = wp[t * ts];
-#pragma unroll 1
-  for (int kg = 0; kg < KG; ++kg) {
-    const float4 x = *reinterpret_cast<const float4*>(xrow + 16 * kg);
-    const int kn = (kg + 1 < KG) ? kg + 1 : kg;
-    float4 wn[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) wn[t] = wp[t * ts + (size_t)kn * 64];
-#define PMG_STEP(C)                                                                              \
+  const unsigned ts = (unsigned)KG * 1024u;  // bytes per tile
+  float4 wa[NT], wb[NT];
+#define PMG_LOAD(dst, kgi) \
+  _Pragma("unroll") for (int t = 0; t < NT; ++t) dst[t] = pmg_bload(rs, voff, soff + t * ts + (unsigned)(kgi) * 1024u);
+#define PMG_STEP(wc, C)                                                                          \
   _Pragma("unroll") for (int uu = 0; uu < TPP; ++uu) {                                           \
     ar[u0 + uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[3 * uu + 0].C, x.C, ar[u0 + uu], 0, 0, 0); \
     az[u0 + uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[3 * uu + 1].C, x.C, az[u0 + uu], 0, 0, 0); \
     at[u0 + uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[3 * uu + 2].C, x.C, at[u0 + uu], 0, 0, 0); \
   }
-    PMG_STEP(x) PMG_STEP(y) PMG_STEP(z) PMG_STEP(w)
-#undef PMG_STEP
-#pragma unroll
-    for (int t = 0; t < NT; ++t) wc[t] = wn[t];
+  PMG_LOAD(wa, 0)
+#pragma unroll 1
+  for (int kg = 0; kg < KG; kg += 2) {
+    PMG_LOAD(wb, kg + 1)
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const float4 x = *reinterpret_cast<const float4*>(xrow + 16 * kg);
+      PMG_STEP(wa, x) PMG_STEP(wa, y) PMG_STEP(wa, z) PMG_STEP(wa, w)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int kn = (kg + 2 < KG) ? kg + 2 : kg;
+      PMG_LOAD(wa, kn)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const float4 x = *reinterpret_cast<const float4*>(xrow + 16 * kg + 16);
+      PMG_STEP(wb, x) PMG_STEP(wb, y) PMG_STEP(wb, z) PMG_STEP(wb, w)
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
+#undef PMG_STEP
+#undef PMG_LOAD
 }
 
 template <int UPW, int TPP>
 __device__ __forceinline__ void gemm3(f32x4 (&ar)[UPW], f32x4 (&az)[UPW], f32x4 (&at)[UPW],
-                                      const float4* __restrict__ wbase, const int KG, const float* xrow,
-                                      const int wave, const int lane) {
+                                      const __amdgpu_buffer_rsrc_t rs, const unsigned voff, const unsigned obase,
+                                      const int KG, const float* xrow, const int wave) {
   // this wave's tiles: 3*(wave*UPW + u), u in [0,UPW)
 #pragma unroll
   for (int ps = 0; ps < UPW / TPP; ++ps) {
     const int u0 = ps * TPP;
-    const float4* wp = wbase + ((size_t)(3 * (wave * UPW + u0)) * KG) * 64 + lane;
-    gemm3_pass<UPW, TPP>(ar, az, at, u0, wp, KG, xrow);
+    const unsigned soff = obase + (unsigned)(3 * (wave * UPW + u0)) * (unsigned)KG * 1024u;
+    gemm3_pass<UPW, TPP>(ar, az, at, u0, rs, voff, soff, KG, xrow);
   }
 }
 
 // One 16-row output tile, K = KG*16, two interleaved accumulators.
-__device__ __forceinline__ f32x4 gemm1(f32x4 acc, const float4* __restrict__ wp, const int KG, const float* xrow) {
+__device__ __forceinline__ f32x4 gemm1(f32x4 acc, const __amdgpu_buffer_rsrc_t rs, const unsigned voff,
+                                       const unsigned soff, const int KG, const float* xrow) {
   f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
+#pragma unroll 2
   for (int kg = 0; kg < KG; kg += 2) {
     const float4 x0 = *reinterpret_cast<const float4*>(xrow + 16 * kg);
     const float4 x1 = *reinterpret_cast<const float4*>(xrow + 16 * kg + 16);
-    const float4 w0 = wp[(size_t)kg * 64];
-    const float4 w1 = wp[(size_t)kg * 64 + 64];
+    const float4 w0 = pmg_bload(rs, voff, soff + (unsigned)kg * 1024u);
+    const float4 w1 = pmg_bload(rs, voff, soff + (unsigned)kg * 1024u + 1024u);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, x0.x, acc, 0, 0, 0);
     acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, x1.x, acc2, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, x0.y, acc, 0, 0, 0);
@@ -106,10 +123,13 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
   const int b = lane & 15, q = lane >> 4;
   const int g = blockIdx.x;
   const int row0 = g * PMG_ROWS;
+  const __amdgpu_buffer_rsrc_t wrs = pmg_rsrc(a.wbase, a.wbytes);
+  const unsigned voff = (unsigned)lane * 16u;
   const bool teacher = (a.mode == PMG_FWD_TEACHER);
   const bool decode = (a.mode == PMG_FWD_DECODE);
   const bool stepm = (a.mode == PMG_FWD_STEP);
-  const bool keep = teacher;  // keep per-step history for the backward
+  const bool keep = teacher && !(a.dbg & 0x1000);  // keep per-step history for the backward
+  const int dbg = a.dbg;
 
   // ---------------------------------------------------------------- init
   for (int idx = tid; idx < 16 * PMG_XTP; idx += PMG_THREADS) xtop[idx] = 0.0f;
@@ -124,7 +144,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     __syncthreads();
     for (int t = wave; t < UT; t += PMG_WAVES) {
       f32x4 acc = ld4(a.b_l2h + 16 * t + 4 * q);
-      acc = gemm1(acc, a.L2Hp + ((size_t)t * (a.Z / 16)) * 64 + lane, a.Z / 16, lat + b * ZP + 4 * q);
+      acc = gemm1(acc, wrs, voff, a.oL2H + (unsigned)t * (unsigned)(a.Z / 16) * 1024u, a.Z / 16, lat + b * ZP + 4 * q);
       for (int l = 0; l < L; ++l) st4(&h_lds[(size_t)(l * 16 + b) * HP + 16 * t + 4 * q], acc);
     }
   } else {
@@ -169,18 +189,18 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
 
   for (int i = 0;; ++i) {
     // ------------------------------------------------------------ extras GEMM
-    {
+    if (!(dbg & 0x200)) {
       const float* xrow = h_lds + (size_t)((L - 1) * 16 + b) * HP + 4 * q;
       for (int xt = wave; xt < a.NXT; xt += PMG_WAVES) {
         f32x4 acc = ld4(a.BX + 16 * xt + 4 * q);
-        acc = gemm1(acc, a.WXp + ((size_t)xt * KGH) * 64 + lane, KGH, xrow);
+        acc = gemm1(acc, wrs, voff, a.oWX + (unsigned)xt * (unsigned)KGH * 1024u, KGH, xrow);
         st4(&xex[b * XP + 16 * xt + 4 * q], acc);
       }
     }
     __syncthreads();  // B1
 
     // ------------------------------------------------------------ consume logits of step i-1
-    if (i >= 1 && wave == 0) {
+    if (i >= 1 && wave == 0 && !(dbg & 0x2000)) {
       const int bb = lane >> 2, s = lane & 3;
       const int row = row0 + bb;
       const bool rowok = row < B;
@@ -264,14 +284,14 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     if (i == N) break;
 
     // ------------------------------------------------------------ stack update
-    {
+    if (!(dbg & 0x100)) {
       const int ncol = W * 4;
       int dsplit = PMG_THREADS / ncol;
       if (dsplit < 1) dsplit = 1;
       if (dsplit > D) dsplit = D;
       const int dch = (D + dsplit - 1) / dsplit;
-      const int slot_old = keep ? i : (i & 1);
-      const int slot_new = keep ? i + 1 : ((i + 1) & 1);
+      const int slot_old = teacher ? i : (i & 1);
+      const int slot_new = teacher ? i + 1 : ((i + 1) & 1);
       const float* Sold = a.SB + ((size_t)slot_old * G + g) * a.SW;
       float* Snew = a.SB + ((size_t)slot_new * G + g) * a.SW;
       const bool zero_old = (i == 0) && s_zero;
@@ -330,7 +350,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
       ai[u] = ld4(a.BG[0] + 2 * H + j0);
       ah[u] = ld4(a.BG[0] + 3 * H + j0);
     }
-    gemm3<UPW, TPP>(ar, az, ah, a.WHHp[0], KGH, h_lds + (size_t)b * HP + 4 * q, wave, lane);
+    if (!(dbg & 0x400)) gemm3<UPW, TPP>(ar, az, ah, wrs, voff, a.oWHH[0], KGH, h_lds + (size_t)b * HP + 4 * q, wave);
     __syncthreads();  // B2: stack top + token visible; every read of h_lds[0] (old) is done
 
     if (decode && misc[16]) {
@@ -343,7 +363,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     }
 
     // ------------------------------------------------------------ layer 0: stack-top GEMM, table, gates
-    gemm3<UPW, TPP>(ar, az, ai, a.WIHp[0], PMG_KS / 16, xtop + b * PMG_XTP + 4 * q, wave, lane);
+    if (!(dbg & 0x800)) gemm3<UPW, TPP>(ar, az, ai, wrs, voff, a.oWIH[0], PMG_KS / 16, xtop + b * PMG_XTP + 4 * q, wave);
     {
       const int tok = misc[b];
       const float* gt = a.GTAB + (size_t)tok * 3 * H;
@@ -387,8 +407,8 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
         ai[u] = ld4(a.BG[l] + 2 * H + j0);
         ah[u] = ld4(a.BG[l] + 3 * H + j0);
       }
-      gemm3<UPW, TPP>(ar, az, ah, a.WHHp[l], KGH, h_lds + (size_t)(l * 16 + b) * HP + 4 * q, wave, lane);
-      gemm3<UPW, TPP>(ar, az, ai, a.WIHp[l], KGH, h_lds + (size_t)((l - 1) * 16 + b) * HP + 4 * q, wave, lane);
+      gemm3<UPW, TPP>(ar, az, ah, wrs, voff, a.oWHH[l], KGH, h_lds + (size_t)(l * 16 + b) * HP + 4 * q, wave);
+      gemm3<UPW, TPP>(ar, az, ai, wrs, voff, a.oWIH[l], KGH, h_lds + (size_t)((l - 1) * 16 + b) * HP + 4 * q, wave);
       __syncthreads();  // every read of h_lds[l] (old) is done
 #pragma unroll
       for (int u = 0; u < UPW; ++u) {

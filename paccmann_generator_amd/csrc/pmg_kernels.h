@@ -44,6 +44,7 @@ hipError_t pmg_launch_aux(const AuxArgs* a, hipStream_t st);
 
 struct FwdArgs {
   int mode;   // PMG_FWD_*
+  int dbg;    // PMG_DEBUG ablation bits (timing experiments only; results are wrong when set)
   int B, G, N;  // N decoder steps
   int H, W, D, V, L, Z, NX, NXT, XP, HP, KGH, VP, SW;
   int start_tok, stop_tok;
@@ -51,10 +52,11 @@ struct FwdArgs {
   uint32_t flags;
   uint64_t seed, offset;
   int64_t seq_base;
-  // packed weights
-  const float4* WXp; const float* BX; const float* GTAB;
-  const float4* WHHp[PMG_MAX_LAYERS]; const float4* WIHp[PMG_MAX_LAYERS]; const float* BG[PMG_MAX_LAYERS];
-  const float4* L2Hp; const float* b_l2h;  // decode
+  // packed weights: one buffer resource over [wbase, wbase + wbytes), byte offsets per matrix
+  const float* wbase; unsigned wbytes;
+  unsigned oWX, oWHH[PMG_MAX_LAYERS], oWIH[PMG_MAX_LAYERS], oL2H;
+  const float* BX; const float* GTAB; const float* BG[PMG_MAX_LAYERS];
+  const float* b_l2h;  // decode
   // inputs
   const float* latent;     // decode: [B][Z]
   const float* h0;         // teacher/step: [L][B][H]
@@ -82,11 +84,13 @@ size_t pmg_fwd_lds_bytes(const FwdArgs* a);
 struct BwdArgs {
   int B, G, N;  // N = T-1 decoder steps
   int H, W, D, V, L, NX, NXT, XP, KGH, VP, SW, UPW;
+  int dbg;      // PMG_DEBUG ablation bits
   float scale;
   const int64_t* tokens;  // [T][B]
   const float* reward;    // [B]
-  // packed transposed weights
-  const float4* WXt; const float4* WHHt[PMG_MAX_LAYERS]; const float4* WIHt[PMG_MAX_LAYERS];
+  // packed transposed weights: one buffer resource, byte offsets per matrix
+  const float* wbase; unsigned wbytes;
+  unsigned oWXt, oWHHt[PMG_MAX_LAYERS], oWIHt[PMG_MAX_LAYERS];
   // history from the forward
   const float* SB; const float* HH[PMG_MAX_LAYERS]; const float* GT[PMG_MAX_LAYERS];
   const float* CT; const float* PV; const float* PR; const float* LP;
