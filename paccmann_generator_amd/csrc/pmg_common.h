@@ -18,6 +18,8 @@
 #define PMG_XTP 72      // LDS pitch of the stack-top tile (64 + 8: conflict-free ds_read_b128)
 #define PMG_CHUNK 128   // hidden units per backward chunk (PMG_WAVES * 16)
 #define PMG_CP 520      // LDS pitch of a backward chunk row (4*128 + 8)
+#define PMG_SBLK 26     // stack rows a thread updates per register burst (forward)
+#define PMG_SBLKB 13    // same for the backward (two arrays in flight)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

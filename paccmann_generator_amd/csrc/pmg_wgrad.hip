@@ -56,9 +56,12 @@ struct WgradArgs {
 namespace {
 
 // Wave tile = (16*MI) x (16*NJ); workgroup = WR x WC waves; TM = 16*MI*WR = 128.
-// The hot loop is branch-free: out-of-range row/column fragments are clamped to row 0 of
-// the slab and their (garbage) results are simply never read back.
-template <int MI, int NJ, int WR, int WC>
+// ONEHOT: the B operand is generated from the token ids (embedding-table job).
+// The hot loop is branch-free: out-of-range row/column fragments are clamped to tile 0 of
+// the slab and their (garbage) results are simply never read back.  Operands stream
+// through buffer resources (SGPR descriptor + one lane-constant VGPR offset + a uniform
+// byte offset per fragment); two register sets keep the next slab in flight.
+template <int MI, int NJ, int WR, int WC, bool ONEHOT>
 __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArgs a) {
   constexpr int TN = 16 * NJ * WC;
   const int tid = threadIdx.x;
@@ -66,44 +69,59 @@ __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArg
   const int lane = tid & 63;
   const int n16 = lane & 15, q = lane >> 4;
   const int wr = wave / WC, wc = wave - wr * WC;
-  const int ntiles = (TN == 128) ? a.tiles_wide : a.tiles_narrow;
+  // tiles of this variant
+  int ntiles = 0;
+  for (int k = 0; k < a.njobs; ++k)
+    if (a.jobs[k].tn == TN && (a.jobs[k].B == nullptr) == ONEHOT) ntiles += a.jobs[k].row_tiles * a.jobs[k].col_tiles;
   // XCD-aware remap: blocks b and b+8 share an XCD; give each XCD a contiguous run of
   // virtual ids so that the tiles of one split (same slabs) meet in one L2.
   const int nblk = gridDim.x;  // multiple of 8
   const int v = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
   if (v >= ntiles * a.S) return;
   const int s = v / ntiles;
-  const int t = v - s * ntiles;
-  int ji = -1;
-  for (int k = 0; k < a.njobs; ++k)
-    if (a.jobs[k].tn == TN && t >= a.jobs[k].tile0) ji = k;
+  int t = v - s * ntiles;
+  int ji = 0;
+  for (int k = 0; k < a.njobs; ++k) {
+    if (a.jobs[k].tn == TN && (a.jobs[k].B == nullptr) == ONEHOT) {
+      const int nt = a.jobs[k].row_tiles * a.jobs[k].col_tiles;
+      if (t < nt) { ji = k; break; }
+      t -= nt;
+    }
+  }
   const WJob& jb = a.jobs[ji];
-  const int tl = t - jb.tile0;
+  const int tl = t;
   const int rt = tl / jb.col_tiles, ct = tl - rt * jb.col_tiles;
   const int r0 = rt * WG_TM + wr * 16 * MI;
   const int c0 = ct * TN + wc * 16 * NJ;
   const int H = a.H, G = a.G;
 
-  size_t aoff[MI], boff[NJ];
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    int rr = r0 + 16 * i + n16;
-    if (r0 + 16 * i >= jb.rows) rr = n16;  // clamp: result rows are ignored
-    if (jb.skip_mid && rr >= 2 * H) rr += H;
-    aoff[i] = (size_t)rr * 16 + 4 * q;
-  }
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    int cc = c0 + 16 * j + n16;
-    if (c0 + 16 * j >= jb.cols) cc = n16;
-    boff[j] = (size_t)cc * 16 + 4 * q;
-  }
-  const bool onehot = (jb.B == nullptr);
-
   const int nslab = jb.P * G;
   const int per = (nslab + a.S - 1) / a.S;
   const int sl0 = s * per;
   const int sl1 = (sl0 + per < nslab) ? sl0 + per : nslab;
+  const int ns = sl1 - sl0;
+
+  // uniform byte offsets of each fragment's 16-row tile inside a slab
+  unsigned arow[MI], brow[NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    int rr = r0 + 16 * i;
+    if (rr >= jb.rows) rr = 0;  // clamp: result rows are ignored
+    if (jb.skip_mid && rr >= 2 * H) rr += H;
+    arow[i] = (unsigned)rr * 64u;
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    int cc = c0 + 16 * j;
+    if (cc >= jb.cols) cc = 0;
+    brow[j] = (unsigned)cc * 64u;
+  }
+  const unsigned voff = (unsigned)(n16 * 16 + 4 * q) * 4u;
+  const unsigned astr = (unsigned)jb.a_rows * 64u, bstr = (unsigned)jb.b_rows * 64u;
+  const int nsafe = ns > 0 ? ns : 0;
+  const __amdgpu_buffer_rsrc_t ars = pmg_rsrc(jb.A + (size_t)sl0 * jb.a_rows * 16, (unsigned)nsafe * astr);
+  const __amdgpu_buffer_rsrc_t brs =
+      ONEHOT ? ars : pmg_rsrc(jb.B + ((size_t)sl0 + (size_t)jb.b_pshift * G) * jb.b_rows * 16, (unsigned)nsafe * bstr);
 
   f32x4 acc[MI][NJ];
 #pragma unroll
@@ -114,27 +132,22 @@ __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArg
 #pragma unroll
   for (int i = 0; i < MI; ++i) rsum[i] = 0.f;
 
-  const float* Ab = jb.A;
-  const float* Bb = onehot ? nullptr : jb.B + (size_t)jb.b_pshift * G * jb.b_rows * 16;
-  const size_t astr = (size_t)jb.a_rows * 16, bstr = (size_t)jb.b_rows * 16;
-
-  auto load_a = [&](int sl, float4 (&fa)[MI]) {
-    const float* As = Ab + (size_t)sl * astr;
+#define WG_LOAD_A(dst, k) \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i) dst[i] = pmg_bload(ars, voff, (unsigned)(k) * astr + arow[i]);
+  auto load_b = [&](int k, float4 (&fb)[NJ]) {
+    if (!ONEHOT) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const float4*>(As + aoff[i]);
-  };
-  auto load_b = [&](int sl, float4 (&fb)[NJ]) {
-    if (!onehot) {
-      const float* Bs = Bb + (size_t)sl * bstr;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const float4*>(Bs + boff[j]);
+      for (int j = 0; j < NJ; ++j) fb[j] = pmg_bload(brs, voff, (unsigned)k * bstr + brow[j]);
     } else {
+      const int sl = sl0 + k;
       const int p = sl / G, g = sl - p * G;
       int tk[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int row = g * 16 + 4 * q + c;
-        tk[c] = (row < a.B) ? (int)a.tokens[(size_t)p * a.B + row] : -1;
+        const int rc = row < a.B ? row : 0;
+        const int tv = (int)a.tokens[(size_t)p * a.B + rc];
+        tk[c] = row < a.B ? tv : -1;
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -144,30 +157,38 @@ __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArg
       }
     }
   };
-
-  if (sl0 < sl1) {
-    float4 fa[MI], fb[NJ];
-    load_a(sl0, fa);
-    load_b(sl0, fb);
-#pragma unroll 1
-    for (int sl = sl0; sl < sl1; ++sl) {
-      float4 na[MI], nb[NJ];
-      const int sn = (sl + 1 < sl1) ? sl + 1 : sl;
-      load_a(sn, na);
-      load_b(sn, nb);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) rsum[i] += (fa[i].x + fa[i].y) + (fa[i].z + fa[i].w);
-#define WG_STEP(C)                                                                                   \
+#define WG_STEP(fa, fb, C)                                                                           \
   _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)      \
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].C, fb[j].C, acc[i][j], 0, 0, 0);
-      WG_STEP(x) WG_STEP(y) WG_STEP(z) WG_STEP(w)
-#undef WG_STEP
-#pragma unroll
-      for (int i = 0; i < MI; ++i) fa[i] = na[i];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) fb[j] = nb[j];
+#define WG_COMPUTE(fa, fb)                                                                           \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i) rsum[i] += (fa[i].x + fa[i].y) + (fa[i].z + fa[i].w); \
+  WG_STEP(fa, fb, x) WG_STEP(fa, fb, y) WG_STEP(fa, fb, z) WG_STEP(fa, fb, w)
+
+  if (ns > 0) {
+    float4 fa0[MI], fb0[NJ], fa1[MI], fb1[NJ];
+    WG_LOAD_A(fa0, 0)
+    load_b(0, fb0);
+#pragma unroll 1
+    for (int k = 0; k < ns; k += 2) {
+      const int k1 = (k + 1 < ns) ? k + 1 : k;
+      WG_LOAD_A(fa1, k1)
+      load_b(k1, fb1);
+      __builtin_amdgcn_sched_barrier(0);
+      WG_COMPUTE(fa0, fb0)
+      __builtin_amdgcn_sched_barrier(0);
+      const int k2 = (k + 2 < ns) ? k + 2 : k;
+      WG_LOAD_A(fa0, k2)
+      load_b(k2, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k + 1 < ns) {
+        WG_COMPUTE(fa1, fb1)
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+#undef WG_COMPUTE
+#undef WG_STEP
+#undef WG_LOAD_A
 
   // partial tile: [128][TN], element (row_local, col_local)
   float* pt = a.partial + (size_t)s * a.split_stride + jb.pt_off + (size_t)tl * (WG_TM * TN);
@@ -325,13 +346,16 @@ struct JobPlan {
 };
 
 int choose_splits(const PmgDims& d, int total_tiles) {
-  const long slabs = (long)(d.T - 1) * d.G;
+  const long slabs = (long)d.T * d.G;
   long S = 2048 / (total_tiles > 0 ? total_tiles : 1);
   if (S < 1) S = 1;
   if (S > 64) S = 64;
   const long maxS = (slabs + 3) / 4;  // at least ~4 slabs per split
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
+  // one split's slab range is addressed through a 32-bit buffer resource: keep it < 2 GiB
+  const long slab_bytes = (long)4 * d.H * 64;
+  while (((slabs + S - 1) / S) * slab_bytes >= (1L << 31)) S *= 2;
   return (int)S;
 }
 
@@ -410,17 +434,22 @@ hipError_t pmg_run_wgrad(const PmgDims& d, const PmgLayout& lay, float* ws, cons
   w.jobs[k].A = ws + lay.DX; w.jobs[k].B = ws + lay.HH[d.L - 1]; ++k;
 
   hipError_t e = hipSuccess;
-  if (w.tiles_wide > 0) {
-    const int nb = ((w.tiles_wide * w.S + 7) / 8) * 8;
-    hipLaunchKernelGGL((pmg_wgrad_kernel<4, 4, 2, 2>), dim3(nb), dim3(WG_THREADS), 0, st, w);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
+  {
+    int nt[2][2] = {{0, 0}, {0, 0}};  // [wide][onehot]
+    for (int j = 0; j < w.njobs; ++j)
+      nt[w.jobs[j].tn == 128][w.jobs[j].B == nullptr] += w.jobs[j].row_tiles * w.jobs[j].col_tiles;
+#define PMG_WG_LAUNCH(cnt, ...)                                                              \
+  if ((cnt) > 0) {                                                                           \
+    const int nb = (((cnt) * w.S + 7) / 8) * 8;                                              \
+    hipLaunchKernelGGL((pmg_wgrad_kernel<__VA_ARGS__>), dim3(nb), dim3(WG_THREADS), 0, st, w); \
+    e = hipGetLastError();                                                                   \
+    if (e != hipSuccess) return e;                                                           \
   }
-  if (w.tiles_narrow > 0) {
-    const int nb = ((w.tiles_narrow * w.S + 7) / 8) * 8;
-    hipLaunchKernelGGL((pmg_wgrad_kernel<2, 4, 4, 1>), dim3(nb), dim3(WG_THREADS), 0, st, w);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    PMG_WG_LAUNCH(nt[1][0], 4, 4, 2, 2, false)
+    PMG_WG_LAUNCH(nt[1][1], 4, 4, 2, 2, true)
+    PMG_WG_LAUNCH(nt[0][0], 2, 4, 4, 1, false)
+    PMG_WG_LAUNCH(nt[0][1], 2, 4, 4, 1, true)
+#undef PMG_WG_LAUNCH
   }
   {
     size_t total = P.dense_floats;
