@@ -31,10 +31,14 @@ __device__ __forceinline__ void st4(float* p, const f32x4 v) {
 // Two register sets (wa, wb), loop unrolled by two: the loads of group kg+1 are in flight
 // while the MFMAs of group kg run (the sched_barriers keep hipcc from re-fusing load and
 // use, which it otherwise does).  KG is even.
-template <int UPW, int TPP>
+struct NoSide {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+template <int UPW, int TPP, class Side>
 __device__ __forceinline__ void gemm3_pass(f32x4 (&ar)[UPW], f32x4 (&az)[UPW], f32x4 (&at)[UPW], const int u0,
                                            const __amdgpu_buffer_rsrc_t rs, const unsigned voff,
-                                           const unsigned soff, const int KG, const float* xrow) {
+                                           const unsigned soff, const int KG, const float* xrow, Side& side) {
   constexpr int NT = 3 * TPP;
   const unsigned ts = (unsigned)KG * 1024u;  // bytes per tile
   float4 wa[NT], wb[NT];
@@ -66,44 +70,76 @@ __device__ __forceinline__ void gemm3_pass(f32x4 (&ar)[UPW], f32x4 (&az)[UPW], f
       PMG_STEP(wb, x) PMG_STEP(wb, y) PMG_STEP(wb, z) PMG_STEP(wb, w)
     }
     __builtin_amdgcn_sched_barrier(0);
+    side();  // one unit of side work (stack row) per double group, hidden under the MFMAs
+    __builtin_amdgcn_sched_barrier(0);
   }
 #undef PMG_STEP
 #undef PMG_LOAD
 }
 
-template <int UPW, int TPP>
+template <int UPW, int TPP, class Side>
 __device__ __forceinline__ void gemm3(f32x4 (&ar)[UPW], f32x4 (&az)[UPW], f32x4 (&at)[UPW],
                                       const __amdgpu_buffer_rsrc_t rs, const unsigned voff, const unsigned obase,
-                                      const int KG, const float* xrow, const int wave) {
+                                      const int KG, const float* xrow, const int wave, Side& side) {
   // this wave's tiles: 3*(wave*UPW + u), u in [0,UPW)
 #pragma unroll
   for (int ps = 0; ps < UPW / TPP; ++ps) {
     const int u0 = ps * TPP;
     const unsigned soff = obase + (unsigned)(3 * (wave * UPW + u0)) * (unsigned)KG * 1024u;
-    gemm3_pass<UPW, TPP>(ar, az, at, u0, rs, voff, soff, KG, xrow);
+    gemm3_pass<UPW, TPP>(ar, az, at, u0, rs, voff, soff, KG, xrow, side);
   }
 }
 
-// One 16-row output tile, K = KG*16, two interleaved accumulators.
+// One 16-row output tile, K = KG*16 (KG even).  Two register sets of four groups keep four
+// weight loads in flight; two accumulators break the dependent-MFMA chain.
 __device__ __forceinline__ f32x4 gemm1(f32x4 acc, const __amdgpu_buffer_rsrc_t rs, const unsigned voff,
                                        const unsigned soff, const int KG, const float* xrow) {
   f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-  for (int kg = 0; kg < KG; kg += 2) {
-    const float4 x0 = *reinterpret_cast<const float4*>(xrow + 16 * kg);
-    const float4 x1 = *reinterpret_cast<const float4*>(xrow + 16 * kg + 16);
-    const float4 w0 = pmg_bload(rs, voff, soff + (unsigned)kg * 1024u);
-    const float4 w1 = pmg_bload(rs, voff, soff + (unsigned)kg * 1024u + 1024u);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, x0.x, acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, x1.x, acc2, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, x0.y, acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, x1.y, acc2, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, x0.z, acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, x1.z, acc2, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, x0.w, acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, x1.w, acc2, 0, 0, 0);
+  float4 wa[4], wb[4];
+#define G1_LOAD(dst, k0)                                                        \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                               \
+    const int kk = ((k0) + j < KG) ? (k0) + j : KG - 1;                         \
+    dst[j] = pmg_bload(rs, voff, soff + (unsigned)kk * 1024u);                  \
   }
+#define G1_COMP(src, k0)                                                        \
+  _Pragma("unroll") for (int j = 0; j < 4; j += 2) {                            \
+    if ((k0) + j < KG) {                                                        \
+      const float4 x0 = *reinterpret_cast<const float4*>(xrow + 16 * ((k0) + j));      \
+      const float4 x1 = *reinterpret_cast<const float4*>(xrow + 16 * ((k0) + j) + 16); \
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(src[j].x, x0.x, acc, 0, 0, 0);        \
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(src[j + 1].x, x1.x, acc2, 0, 0, 0);  \
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(src[j].y, x0.y, acc, 0, 0, 0);        \
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(src[j + 1].y, x1.y, acc2, 0, 0, 0);  \
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(src[j].z, x0.z, acc, 0, 0, 0);        \
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(src[j + 1].z, x1.z, acc2, 0, 0, 0);  \
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(src[j].w, x0.w, acc, 0, 0, 0);        \
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(src[j + 1].w, x1.w, acc2, 0, 0, 0);  \
+    }                                                                           \
+  }
+  G1_LOAD(wa, 0)
+#pragma unroll 1
+  for (int kg = 0; kg < KG; kg += 8) {
+    G1_LOAD(wb, kg + 4)
+    __builtin_amdgcn_sched_barrier(0);
+    G1_COMP(wa, kg)
+    __builtin_amdgcn_sched_barrier(0);
+    G1_LOAD(wa, kg + 8)
+    __builtin_amdgcn_sched_barrier(0);
+    G1_COMP(wb, kg + 4)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef G1_LOAD
+#undef G1_COMP
   return acc + acc2;
+}
+
+// Gate non-linearities on the hardware exp/rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each).
+// Absolute error ~1e-7, the same order as the GEMM summation-order noise.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __expf(-2.0f * fabsf(x));
+  const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+  return copysignf(t, x);
 }
 
 template <int UPW, int TPP>
@@ -187,7 +223,44 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
 
   f32x4 ar[UPW], az[UPW], ai[UPW], ah[UPW];
 
+  // stack update work split: thread -> (column w, row quad bq, depth range [st_d0, st_d1))
+  int st_bq, st_w, st_d0, st_d1, st_rows, st_dch;
+  bool st_has;
+  size_t st_cofs;
+  {
+    const int ncol = W * 4;  // <= 256 (pmg_check_shape caps W at 64): one item per thread
+    int dsplit = PMG_THREADS / ncol;
+    if (dsplit > D) dsplit = D;
+    st_dch = (D + dsplit - 1) / dsplit;
+    st_bq = tid & 3;
+    const int cw = tid >> 2;
+    st_w = cw % W;
+    const int part = cw / W;
+    st_d0 = part * st_dch;
+    st_d1 = (st_d0 + st_dch < D) ? st_d0 + st_dch : D;
+    st_has = (tid < ncol * dsplit) && (st_d0 < st_d1);
+    st_rows = st_d1 - st_d0;
+    st_cofs = (size_t)st_w * 16 + 4 * st_bq;
+  }
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  NoSide no_side;
+
   for (int i = 0;; ++i) {
+    // ------------------------------------------------------------ stack: first rows requested early
+    const int st_slot_old = teacher ? i : (i & 1);
+    const int st_slot_new = teacher ? i + 1 : ((i + 1) & 1);
+    const float* const st_Sold = a.SB + ((size_t)st_slot_old * G + g) * a.SW + st_cofs;
+    const bool st_on = st_has && !(dbg & 0x100) && i < N;
+    const bool st_ldok = !((i == 0) && s_zero);
+    f32x4 s_prev = zero4, s_cur = zero4, r0 = zero4, r1 = zero4, r2 = zero4;
+    if (st_on && st_ldok) {
+      if (st_d0 > 0) s_prev = ld4(st_Sold + (size_t)(st_d0 - 1) * W * 16);
+      s_cur = ld4(st_Sold + (size_t)st_d0 * W * 16);
+      if (st_d0 + 1 < D) r0 = ld4(st_Sold + (size_t)(st_d0 + 1) * W * 16);
+      if (st_d0 + 2 < D) r1 = ld4(st_Sold + (size_t)(st_d0 + 2) * W * 16);
+      if (st_d0 + 3 < D) r2 = ld4(st_Sold + (size_t)(st_d0 + 3) * W * 16);
+    }
+
     // ------------------------------------------------------------ extras GEMM
     if (!(dbg & 0x200)) {
       const float* xrow = h_lds + (size_t)((L - 1) * 16 + b) * HP + 4 * q;
@@ -283,63 +356,59 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     }
     if (i == N) break;
 
-    // ------------------------------------------------------------ stack update
-    if (!(dbg & 0x100)) {
-      const int ncol = W * 4;
-      int dsplit = PMG_THREADS / ncol;
-      if (dsplit < 1) dsplit = 1;
-      if (dsplit > D) dsplit = D;
-      const int dch = (D + dsplit - 1) / dsplit;
-      const int slot_old = teacher ? i : (i & 1);
-      const int slot_new = teacher ? i + 1 : ((i + 1) & 1);
-      const float* Sold = a.SB + ((size_t)slot_old * G + g) * a.SW;
-      float* Snew = a.SB + ((size_t)slot_new * G + g) * a.SW;
-      const bool zero_old = (i == 0) && s_zero;
-      for (int item = tid; item < ncol * dsplit; item += PMG_THREADS) {
-        const int bq = item & 3;
-        const int cw = item >> 2;
-        const int w = cw % W;
-        const int part = cw / W;
-        const int d0 = part * dch;
-        const int d1 = (d0 + dch < D) ? d0 + dch : D;
-        if (d0 >= d1) continue;
-        f32x4 apush, apop, anoop, pv;
+    // ------------------------------------------------------------ stack update, streamed under the gh GEMM
+    // new[d] = no_op*old[d] + push*old[d-1] + pop*old[d+1]   (old[-1] = push value, old[D] = 0).
+    // Each thread walks its depth range one row per side-job call; rows d0-1 .. d0+3 were
+    // requested before the extras GEMM, every call requests row d+4.
+    f32x4 apush = zero4, apop = zero4, anoop = zero4;
+    float* const st_Snew = a.SB + ((size_t)st_slot_new * G + g) * a.SW + st_cofs;
+    if (st_on) {
+      f32x4 pv;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float* cx = xex + (4 * bq + j) * XP;
-          const float c0 = cx[0], c1 = cx[1], c2 = cx[2];
-          const float m = fmaxf(c0, fmaxf(c1, c2));
-          const float e0 = expf(c0 - m), e1 = expf(c1 - m), e2 = expf(c2 - m);
-          const float inv = 1.0f / ((e0 + e1) + e2);
-          apush[j] = e0 * inv; apop[j] = e1 * inv; anoop[j] = e2 * inv;
-          pv[j] = tanhf(cx[3 + w]);
-        }
-        if (keep && part == 0) {
-          if (w == 0) {
+      for (int j = 0; j < 4; ++j) {
+        const float* cx = xex + (4 * st_bq + j) * XP;
+        const float c0 = cx[0], c1 = cx[1], c2 = cx[2];
+        const float m = fmaxf(c0, fmaxf(c1, c2));
+        const float e0 = __expf(c0 - m), e1 = __expf(c1 - m), e2 = __expf(c2 - m);
+        const float inv = 1.0f / ((e0 + e1) + e2);
+        apush[j] = e0 * inv; apop[j] = e1 * inv; anoop[j] = e2 * inv;
+        pv[j] = fast_tanh(cx[3 + st_w]);
+      }
+      if (st_d0 == 0) {
+        s_prev = pv;
+        if (keep) {
+          if (st_w == 0) {
             float* ct = a.CT + ((size_t)i * G + g) * 64;
-            st4(ct + 0 * 16 + 4 * bq, apush);
-            st4(ct + 1 * 16 + 4 * bq, apop);
-            st4(ct + 2 * 16 + 4 * bq, anoop);
+            st4(ct + 0 * 16 + 4 * st_bq, apush);
+            st4(ct + 1 * 16 + 4 * st_bq, apop);
+            st4(ct + 2 * 16 + 4 * st_bq, anoop);
           }
-          st4(a.PV + ((size_t)i * G + g) * 1024 + w * 16 + 4 * bq, pv);
-        }
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-        f32x4 prev = (d0 == 0) ? pv : (zero_old ? zero4 : ld4(Sold + ((size_t)(d0 - 1) * W + w) * 16 + 4 * bq));
-        f32x4 cur = zero_old ? zero4 : ld4(Sold + ((size_t)d0 * W + w) * 16 + 4 * bq);
-        for (int d = d0; d < d1; ++d) {
-          const f32x4 nxt = (d + 1 < D && !zero_old) ? ld4(Sold + ((size_t)(d + 1) * W + w) * 16 + 4 * bq) : zero4;
-          const f32x4 nw = anoop * cur + apush * prev + apop * nxt;
-          st4(Snew + ((size_t)d * W + w) * 16 + 4 * bq, nw);
-          if (d == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xtop[(4 * bq + j) * PMG_XTP + w] = nw[j];
-            if (keep) st4(a.TP + ((size_t)i * G + g) * 1024 + w * 16 + 4 * bq, nw);
-          }
-          prev = cur;
-          cur = nxt;
+          st4(a.PV + ((size_t)i * G + g) * 1024 + st_w * 16 + 4 * st_bq, pv);
         }
       }
     }
+    int sj = 0;  // side-job calls so far (uniform)
+    auto stack_row = [&]() {
+      const int d = st_d0 + sj;
+      const bool act = st_on && sj < st_rows;
+      const int dn = d + 4;
+      f32x4 ldv = zero4;
+      if (act && st_ldok && dn < D && dn <= st_d1) ldv = ld4(st_Sold + (size_t)dn * W * 16);
+      const f32x4 nxt = r0;
+      r0 = r1; r1 = r2; r2 = ldv;
+      if (act) {
+        const f32x4 nw = anoop * s_cur + apush * s_prev + apop * nxt;
+        st4(st_Snew + (size_t)d * W * 16, nw);
+        if (d == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xtop[(4 * st_bq + j) * PMG_XTP + st_w] = nw[j];
+          if (keep) st4(a.TP + ((size_t)i * G + g) * 1024 + st_w * 16 + 4 * st_bq, nw);
+        }
+      }
+      s_prev = s_cur;
+      s_cur = nxt;
+      ++sj;
+    };
 
     // ------------------------------------------------------------ layer 0: gh GEMM
 #pragma unroll
@@ -350,7 +419,8 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
       ai[u] = ld4(a.BG[0] + 2 * H + j0);
       ah[u] = ld4(a.BG[0] + 3 * H + j0);
     }
-    if (!(dbg & 0x400)) gemm3<UPW, TPP>(ar, az, ah, wrs, voff, a.oWHH[0], KGH, h_lds + (size_t)b * HP + 4 * q, wave);
+    if (!(dbg & 0x400)) gemm3<UPW, TPP>(ar, az, ah, wrs, voff, a.oWHH[0], KGH, h_lds + (size_t)b * HP + 4 * q, wave, stack_row);
+    while (sj < st_dch) stack_row();  // rows the GEMM loop did not reach
     __syncthreads();  // B2: stack top + token visible; every read of h_lds[0] (old) is done
 
     if (decode && misc[16]) {
@@ -363,7 +433,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     }
 
     // ------------------------------------------------------------ layer 0: stack-top GEMM, table, gates
-    if (!(dbg & 0x800)) gemm3<UPW, TPP>(ar, az, ai, wrs, voff, a.oWIH[0], PMG_KS / 16, xtop + b * PMG_XTP + 4 * q, wave);
+    if (!(dbg & 0x800)) gemm3<UPW, TPP>(ar, az, ai, wrs, voff, a.oWIH[0], PMG_KS / 16, xtop + b * PMG_XTP + 4 * q, wave, no_side);
     {
       const int tok = misc[b];
       const float* gt = a.GTAB + (size_t)tok * 3 * H;
@@ -380,9 +450,9 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
         f32x4 r, z, n, hn;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          r[j] = pmg_sigmoid(vr[j]);
-          z[j] = pmg_sigmoid(vz[j]);
-          n[j] = tanhf(vi[j] + r[j] * vh[j]);
+          r[j] = fast_sigmoid(vr[j]);
+          z[j] = fast_sigmoid(vz[j]);
+          n[j] = fast_tanh(vi[j] + r[j] * vh[j]);
           hn[j] = (hp[j] - n[j]) * z[j] + n[j];
         }
         st4(hp_ptr, hn);
@@ -407,8 +477,8 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
         ai[u] = ld4(a.BG[l] + 2 * H + j0);
         ah[u] = ld4(a.BG[l] + 3 * H + j0);
       }
-      gemm3<UPW, TPP>(ar, az, ah, wrs, voff, a.oWHH[l], KGH, h_lds + (size_t)(l * 16 + b) * HP + 4 * q, wave);
-      gemm3<UPW, TPP>(ar, az, ai, wrs, voff, a.oWIH[l], KGH, h_lds + (size_t)((l - 1) * 16 + b) * HP + 4 * q, wave);
+      gemm3<UPW, TPP>(ar, az, ah, wrs, voff, a.oWHH[l], KGH, h_lds + (size_t)(l * 16 + b) * HP + 4 * q, wave, no_side);
+      gemm3<UPW, TPP>(ar, az, ai, wrs, voff, a.oWIH[l], KGH, h_lds + (size_t)((l - 1) * 16 + b) * HP + 4 * q, wave, no_side);
       __syncthreads();  // every read of h_lds[l] (old) is done
 #pragma unroll
       for (int u = 0; u < UPW; ++u) {
@@ -419,9 +489,9 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
         f32x4 r, z, n, hn;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          r[j] = pmg_sigmoid(ar[u][j]);
-          z[j] = pmg_sigmoid(az[u][j]);
-          n[j] = tanhf(ai[u][j] + r[j] * ah[u][j]);
+          r[j] = fast_sigmoid(ar[u][j]);
+          z[j] = fast_sigmoid(az[u][j]);
+          n[j] = fast_tanh(ai[u][j] + r[j] * ah[u][j]);
           hn[j] = (hp[j] - n[j]) * z[j] + n[j];
         }
         st4(hp_ptr, hn);
