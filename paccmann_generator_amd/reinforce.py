@@ -24,7 +24,7 @@ from typing import Callable, Optional
 import numpy as np
 import torch
 
-from . import ops
+from . import dp, ops
 from .decoder import SamplingSearch
 
 
@@ -146,25 +146,13 @@ class Reinforce(object):
     # ------------------------------------------------------------------ learning
     def _all_reduce_gradients(self, extra_params=()):
         """One RCCL all-reduce (sum) of the flat gradient buffer."""
-        import torch.distributed as dist
-        params = [p for p in list(self.generator.decoder.parameters()) + list(extra_params) if p.grad is not None]
-        if not params:
-            return
-        flat = torch.cat([p.grad.reshape(-1) for p in params])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
-        off = 0
-        for p in params:
-            n = p.numel()
-            p.grad.copy_(flat[off:off + n].view_as(p.grad))
-            off += n
+        dp.all_reduce_gradients_(list(self.generator.decoder.parameters()) + list(extra_params),
+                                 group=self.process_group)
 
     def _global_count(self, n: int) -> int:
         if self.process_group is None:
             return n
-        import torch.distributed as dist
-        t = torch.tensor([float(n)], device=self.device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group)
-        return int(t.item())
+        return int(round(dp.global_sum(n, self.device, self.process_group)))
 
     def learn(self, latent_z, padded_nums, valid_idx, rewards, lrps: int = 1, n_valid_global=None):
         """reinforce_omics.py:301-342 given sampled + scored molecules.

@@ -1,0 +1,95 @@
+"""The C-ABI library loads on a machine without a GPU and exports every entry point that
+include/pmg.h declares; the host-only entry points (shape check, workspace size, error
+text) behave as documented.  No compute call is made."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'pmg.h')
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(pmg_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    assert declared_functions() == sorted([
+        'pmg_abi_version', 'pmg_strerror', 'pmg_check_shape', 'pmg_workspace_bytes', 'pmg_decode',
+        'pmg_logprob_fwd', 'pmg_reinforce_bwd', 'pmg_step'])
+
+
+def test_library_exports_every_declared_symbol():
+    from paccmann_generator_amd import _ffi
+    assert os.path.exists(_ffi.LIB_PATH)
+    lib = C.CDLL(_ffi.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    assert sorted(_ffi.EXPORTS) == declared_functions()
+    assert lib.pmg_abi_version() == _ffi.PMG_ABI_VERSION
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must be valid C99 without HIP or torch."""
+    import subprocess
+    src = tmp_path / 't.c'
+    src.write_text('#include "pmg.h"\nint main(void){pmg_shape s; pmg_weights w; pmg_grads g; (void)s;(void)w;(void)g;'
+                   'return sizeof(s) == 40 ? 0 : 1;}\n')
+    exe = tmp_path / 't'
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), str(src), '-o',
+                           str(exe)])
+    assert subprocess.call([str(exe)]) == 0
+
+
+def test_ctypes_structs_match_the_header_layout():
+    from paccmann_generator_amd import _ffi
+    assert C.sizeof(_ffi.PmgShape) == 40
+    ptr = C.sizeof(C.c_void_p)
+    assert C.sizeof(_ffi.PmgWeights) == ptr * (1 + 4 * _ffi.PMG_MAX_LAYERS + 8)
+    assert C.sizeof(_ffi.PmgGrads) == ptr * (1 + 4 * _ffi.PMG_MAX_LAYERS + 6)
+
+
+def test_shape_checks_and_error_text():
+    from paccmann_generator_amd import _ffi
+    ok = _ffi.make_shape(4096, 130, 512, 128, 50, 50, 60, 1, 256, 0)
+    assert _ffi.lib.pmg_check_shape(C.byref(ok), _ffi.PMG_MODE_TRAIN) == 0
+    assert _ffi.lib.pmg_check_shape(C.byref(ok), _ffi.PMG_MODE_DECODE) == 0
+    assert _ffi.lib.pmg_check_shape(C.byref(ok), 7) < 0
+    bad = [
+        _ffi.make_shape(8, 4, 100, 16, 10, 7, 23, 1, 32, 0),     # H not supported
+        _ffi.make_shape(8, 4, 128, 16, 65, 7, 23, 1, 32, 0),     # W > 64
+        _ffi.make_shape(8, 4, 128, 16, 10, 7, 250, 1, 32, 0),    # 3+W+V > 256
+        _ffi.make_shape(8, 4, 128, 16, 10, 7, 23, 5, 32, 0),     # L > 4
+        _ffi.make_shape(0, 4, 128, 16, 10, 7, 23, 1, 32, 0),     # empty batch
+        _ffi.make_shape(8, 1, 128, 16, 10, 7, 23, 1, 32, 0),     # train needs T >= 2
+    ]
+    codes = set()
+    for s in bad:
+        rc = _ffi.lib.pmg_check_shape(C.byref(s), _ffi.PMG_MODE_TRAIN)
+        assert rc < 0
+        codes.add(rc)
+        assert len(_ffi.lib.pmg_strerror(rc)) > 3
+        with pytest.raises(_ffi.PmgError):
+            _ffi.workspace_bytes(s, _ffi.PMG_MODE_TRAIN)
+    assert len(codes) >= 5
+    assert _ffi.lib.pmg_check_shape(None, 0) < 0
+
+
+def test_workspace_size_scales_with_batch_and_time():
+    from paccmann_generator_amd import _ffi
+    a = _ffi.workspace_bytes(_ffi.make_shape(4096, 130, 512, 128, 50, 50, 60, 1, 256, 0), _ffi.PMG_MODE_TRAIN)
+    b = _ffi.workspace_bytes(_ffi.make_shape(2048, 130, 512, 128, 50, 50, 60, 1, 256, 0), _ffi.PMG_MODE_TRAIN)
+    d = _ffi.workspace_bytes(_ffi.make_shape(4096, 128, 512, 128, 50, 50, 60, 1, 256, 0), _ffi.PMG_MODE_DECODE)
+    assert 10e9 < a < 24e9 and 0.45 < b / a < 0.6
+    assert d < 0.2e9   # decode keeps two stack slabs per row group, no history
+
+
+def test_cpu_tensors_are_rejected_not_routed_elsewhere():
+    import torch
+    from paccmann_generator_amd import _ffi
+    with pytest.raises(_ffi.PmgError):
+        _ffi._ptr(torch.zeros(4))
