@@ -116,6 +116,20 @@ def cpu_baseline(cfg, budget_s=20.0):
                        f'(same model shape), {el:.1f}s')
 
 
+def pmc_traffic(config, B, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json, made by profiles/summarize_pmc.py); None when the committed
+    passes were taken at another configuration."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            t = json.load(f)
+        if t.get('config') != config or t.get('batch') != B:
+            return None
+        return t['kernels'][kernel]['total_GB'] * 1e9
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def time_phases(learner, cfg, latent, rewards, B, reps=3):
     """Per-kernel durations with HIP events on the launch stream (torch's current stream)."""
     import ctypes as C
@@ -263,8 +277,8 @@ def main():
             dom = max(ph, key=lambda k: ph[k])
             ach = B * steps[dom] * F / (ph[dom] * 1e-3) / 1e12
             result['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
-                                  'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
-                                  'ms': ph[dom]}
+                                  'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
+                                  'traffic': pmc_traffic(args.config, B, dom), 'ms': ph[dom]}
             result['phase_ms'] = ph
             result['phase_tflops'] = {k: B * steps[k] * F / (v * 1e-3) / 1e12 for k, v in ph.items()}
         if world == 1 and not args.no_cpu_baseline:
