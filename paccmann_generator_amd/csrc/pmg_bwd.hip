@@ -208,11 +208,19 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
 
     // ------------------------------------------------------------ stack backward
     if (!virt && !(dbg & 0x100)) {
+      // Live rows (see the forward): S_{p-1} holds data in rows <= min(p-1, N-p), the incoming
+      // gradient (w.r.t. S_p) in rows <= min(p, N-1-p); gradients of rows that are constant zero
+      // or can no longer reach a stack top are neither needed nor formed.
+      const bool full = (dbg & 0x4000) != 0;
+      const int mn = (p < N - p) ? p : N - p;
+      const int nrows = (full || mn > D - 1) ? D : mn + 1;
+      const int s_hi = full ? D - 1 : ((p - 1 < N - p ? p - 1 : N - p) < D - 1 ? (p - 1 < N - p ? p - 1 : N - p) : D - 1);
+      const int g_hi = full ? D - 1 : ((p < N - 1 - p ? p : N - 1 - p) < D - 1 ? (p < N - 1 - p ? p : N - 1 - p) : D - 1);
       const int ncol = W * 4;
       int dsplit = PMG_THREADS / ncol;
       if (dsplit < 1) dsplit = 1;
-      if (dsplit > D) dsplit = D;
-      const int dch = (D + dsplit - 1) / dsplit;
+      if (dsplit > nrows) dsplit = nrows;
+      const int dch = (nrows + dsplit - 1) / dsplit;
       const float* Sprev = a.SB + ((size_t)p * G + g) * a.SW;
       const float* dSin = a.DS + ((size_t)((p + 1) & 1) * G + g) * a.SW;
       float* dSout = a.DS + ((size_t)(p & 1) * G + g) * a.SW;
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
         const int w = cw % W;
         const int part = cw / W;
         const int d0 = part * dch;
-        const int d1 = (d0 + dch < D) ? d0 + dch : D;
+        const int d1 = (d0 + dch < nrows) ? d0 + dch : nrows;
         if (d0 >= d1) continue;
         const f32x4 apush = ld4(ct + 0 * 16 + 4 * bq), apop = ld4(ct + 1 * 16 + 4 * bq),
                     anoop = ld4(ct + 2 * 16 + 4 * bq);
@@ -236,10 +244,10 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
 #pragma unroll
         for (int j = 0; j < 4; ++j) dtop4[j] = dtl[(4 * bq + j) * PMG_XTP + w];
         const size_t cofs = (size_t)w * 16 + 4 * bq;
-#define LD_S(dd) (((dd) < 0 || (dd) >= D || zero_S) ? zero4 : ld4(Sprev + (size_t)(dd) * W * 16 + cofs))
+#define LD_S(dd) (((dd) < 0 || (dd) > s_hi || zero_S) ? zero4 : ld4(Sprev + (size_t)(dd) * W * 16 + cofs))
 #define LD_G(dd)                                                                              \
   (((dd) < 0 || (dd) >= D) ? zero4                                                            \
-                           : ((zero_dS ? zero4 : ld4(dSin + (size_t)(dd) * W * 16 + cofs)) + \
+                           : (((zero_dS || (dd) > g_hi) ? zero4 : ld4(dSin + (size_t)(dd) * W * 16 + cofs)) + \
                               (((dd) == 0) ? dtop4 : zero4)))
         f32x4 gm = LD_G(d0 - 1), gc = LD_G(d0);
         f32x4 sm = (d0 == 0) ? pv : LD_S(d0 - 1);

@@ -223,23 +223,20 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
 
   f32x4 ar[UPW], az[UPW], ai[UPW], ah[UPW];
 
-  // stack update work split: thread -> (column w, row quad bq, depth range [st_d0, st_d1))
-  int st_bq, st_w, st_d0, st_d1, st_rows, st_dch;
-  bool st_has;
+  // stack update work split: thread -> (column w, row quad bq, depth part); the depth range of a
+  // part is recomputed every step from the number of live rows (see below)
+  int st_bq, st_w, st_part, st_dsplit;
+  bool st_col;
   size_t st_cofs;
   {
     const int ncol = W * 4;  // <= 256 (pmg_check_shape caps W at 64): one item per thread
-    int dsplit = PMG_THREADS / ncol;
-    if (dsplit > D) dsplit = D;
-    st_dch = (D + dsplit - 1) / dsplit;
+    st_dsplit = PMG_THREADS / ncol;
+    if (st_dsplit > D) st_dsplit = D;
     st_bq = tid & 3;
     const int cw = tid >> 2;
     st_w = cw % W;
-    const int part = cw / W;
-    st_d0 = part * st_dch;
-    st_d1 = (st_d0 + st_dch < D) ? st_d0 + st_dch : D;
-    st_has = (tid < ncol * dsplit) && (st_d0 < st_d1);
-    st_rows = st_d1 - st_d0;
+    st_part = cw / W;
+    st_col = tid < ncol * st_dsplit;
     st_cofs = (size_t)st_w * 16 + 4 * st_bq;
   }
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -250,15 +247,30 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     const int st_slot_old = teacher ? i : (i & 1);
     const int st_slot_new = teacher ? i + 1 : ((i + 1) & 1);
     const float* const st_Sold = a.SB + ((size_t)st_slot_old * G + g) * a.SW + st_cofs;
-    const bool st_on = st_has && !(dbg & 0x100) && i < N;
-    const bool st_ldok = !((i == 0) && s_zero);
+    // Live rows.  Entering step i only rows 0..i-1 of a stack that started at zero can be non-zero,
+    // and row d of the new stack can reach the stack top (the only way the stack is ever read) no
+    // earlier than step i+d: rows beyond min(i, N-1-i) are neither computed nor stored, and rows
+    // of the old slab beyond st_old_hi are read as zero (they were never written).  The step form
+    // returns the whole stack, so it computes every row.
+    int st_hi = D - 1, st_old_hi = D - 1;
+    if (s_zero) st_old_hi = (i - 1 < st_old_hi) ? i - 1 : st_old_hi;
+    if (!stepm && !(dbg & 0x4000)) {
+      if (N - 1 - i < st_hi) st_hi = N - 1 - i;
+      if (s_zero && i < st_hi) st_hi = i;
+    }
+    const int st_nrows = st_hi + 1;
+    const int st_dch = (st_nrows + st_dsplit - 1) / st_dsplit;
+    const int st_d0 = st_part * st_dch;
+    const int st_d1 = (st_d0 + st_dch < st_nrows) ? st_d0 + st_dch : st_nrows;
+    const int st_rows = st_d1 - st_d0;
+    const bool st_on = st_col && st_d0 < st_d1 && !(dbg & 0x100) && i < N;
     f32x4 s_prev = zero4, s_cur = zero4, r0 = zero4, r1 = zero4, r2 = zero4;
-    if (st_on && st_ldok) {
-      if (st_d0 > 0) s_prev = ld4(st_Sold + (size_t)(st_d0 - 1) * W * 16);
-      s_cur = ld4(st_Sold + (size_t)st_d0 * W * 16);
-      if (st_d0 + 1 < D) r0 = ld4(st_Sold + (size_t)(st_d0 + 1) * W * 16);
-      if (st_d0 + 2 < D) r1 = ld4(st_Sold + (size_t)(st_d0 + 2) * W * 16);
-      if (st_d0 + 3 < D) r2 = ld4(st_Sold + (size_t)(st_d0 + 3) * W * 16);
+    if (st_on) {
+      if (st_d0 > 0 && st_d0 - 1 <= st_old_hi) s_prev = ld4(st_Sold + (size_t)(st_d0 - 1) * W * 16);
+      if (st_d0 <= st_old_hi) s_cur = ld4(st_Sold + (size_t)st_d0 * W * 16);
+      if (st_d0 + 1 <= st_old_hi) r0 = ld4(st_Sold + (size_t)(st_d0 + 1) * W * 16);
+      if (st_d0 + 2 <= st_old_hi) r1 = ld4(st_Sold + (size_t)(st_d0 + 2) * W * 16);
+      if (st_d0 + 3 <= st_old_hi) r2 = ld4(st_Sold + (size_t)(st_d0 + 3) * W * 16);
     }
 
     // ------------------------------------------------------------ extras GEMM
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
       const bool act = st_on && sj < st_rows;
       const int dn = d + 4;
       f32x4 ldv = zero4;
-      if (act && st_ldok && dn < D && dn <= st_d1) ldv = ld4(st_Sold + (size_t)dn * W * 16);
+      if (act && dn <= st_old_hi && dn <= st_d1) ldv = ld4(st_Sold + (size_t)dn * W * 16);
       const f32x4 nxt = r0;
       r0 = r1; r1 = r2; r2 = ldv;
       if (act) {
