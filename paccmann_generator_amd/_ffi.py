@@ -21,7 +21,8 @@ PMG_FLAG_ONLY_WGRAD = 8
 PMG_ABI_VERSION = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libpmg.so')
+# PMG_LIB selects a tuning variant built by __graft_entry__.build(extra_flags=..., libname=...)
+LIB_PATH = os.environ.get('PMG_LIB') or os.path.join(_HERE, 'lib', 'libpmg.so')
 
 
 class PmgShape(C.Structure):

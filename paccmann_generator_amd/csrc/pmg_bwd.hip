@@ -152,10 +152,10 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
           const int ug = wave * UPW + c;
           const int j0 = 16 * ug + 4 * q;
           const float* gp = gt_base + (size_t)ug * 1024 + lane * 4;
-          const f32x4 r = ld4(gp), z = ld4(gp + 256), n = ld4(gp + 512), ghn = ld4(gp + 768);
+          const f32x4 r = pmg_ld4h<4>(gp), z = pmg_ld4h<4>(gp + 256), n = pmg_ld4h<4>(gp + 512), ghn = pmg_ld4h<4>(gp + 768);
           f32x4 hp;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) hp[j] = hh_base[(size_t)(j0 + j) * 16 + b];
+          for (int j = 0; j < 4; ++j) hp[j] = pmg_ld1h<4>(hh_base + (size_t)(j0 + j) * 16 + b);
           const f32x4 d = dh[c];
           f32x4 dr_pre, dz_pre, dn_pre, dghn;
 #pragma unroll
@@ -175,10 +175,10 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
           if (!(dbg & 0x1000))
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            dg_base[((size_t)(0 * H + j0 + j)) * 16 + b] = dr_pre[j];
-            dg_base[((size_t)(1 * H + j0 + j)) * 16 + b] = dz_pre[j];
-            dg_base[((size_t)(2 * H + j0 + j)) * 16 + b] = dn_pre[j];
-            dg_base[((size_t)(3 * H + j0 + j)) * 16 + b] = dghn[j];
+            pmg_st1h<8>(dg_base + ((size_t)(0 * H + j0 + j)) * 16 + b, dr_pre[j]);
+            pmg_st1h<8>(dg_base + ((size_t)(1 * H + j0 + j)) * 16 + b, dz_pre[j]);
+            pmg_st1h<8>(dg_base + ((size_t)(2 * H + j0 + j)) * 16 + b, dn_pre[j]);
+            pmg_st1h<8>(dg_base + ((size_t)(3 * H + j0 + j)) * 16 + b, dghn[j]);
           }
           __syncthreads();
           // ---- products over this chunk's 3*128 reduction rows
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
 #pragma unroll
         for (int j = 0; j < 4; ++j) dtop4[j] = dtl[(4 * bq + j) * PMG_XTP + w];
         const size_t cofs = (size_t)w * 16 + 4 * bq;
-#define LD_S(dd) (((dd) < 0 || (dd) > s_hi || zero_S) ? zero4 : ld4(Sprev + (size_t)(dd) * W * 16 + cofs))
+#define LD_S(dd) (((dd) < 0 || (dd) > s_hi || zero_S) ? zero4 : pmg_ld4h<4>(Sprev + (size_t)(dd) * W * 16 + cofs))
 #define LD_G(dd)                                                                              \
   (((dd) < 0 || (dd) >= D) ? zero4                                                            \
                            : (((zero_dS || (dd) > g_hi) ? zero4 : ld4(dSin + (size_t)(dd) * W * 16 + cofs)) + \
@@ -252,22 +252,40 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
         f32x4 gm = LD_G(d0 - 1), gc = LD_G(d0);
         f32x4 sm = (d0 == 0) ? pv : LD_S(d0 - 1);
         f32x4 sc = LD_S(d0);
-        for (int d = d0; d < d1; ++d) {
-          const f32x4 gn = LD_G(d + 1);
-          const f32x4 sx = LD_S(d + 1);
-          sn += gc * sc;
-          sp += gc * sm;
-          sq += gc * sx;
-          const f32x4 dprev = anoop * gc + apush * gn + apop * gm;
-          st4(dSout + (size_t)d * W * 16 + cofs, dprev);
-          if (d == 0) {
+        // Bursts of PMG_SBLKB rows: every load of a burst is issued (unconditionally, at a clamped
+        // row; rows outside the live range are replaced by zero afterwards) before the first use,
+        // so a thread has 2*PMG_SBLKB loads in flight instead of 2.
+        const size_t rstr = (size_t)W * 16;
+        for (int d = d0; d < d1; d += PMG_SBLKB) {
+          f32x4 gv[PMG_SBLKB], sv[PMG_SBLKB];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float dv = apush[j] * gc[j];
-              dxl[(4 * bq + j) * XP + 3 + w] = dv * (1.0f - pv[j] * pv[j]);
+          for (int k = 0; k < PMG_SBLKB; ++k) {
+            const int dd = d + 1 + k;
+            const int dc = dd < D ? dd : D - 1;
+            gv[k] = ld4(dSin + (size_t)dc * rstr + cofs);
+            sv[k] = pmg_ld4h<4>(Sprev + (size_t)dc * rstr + cofs);
+          }
+#pragma unroll
+          for (int k = 0; k < PMG_SBLKB; ++k) {
+            const int dd = d + 1 + k;
+            const f32x4 gn = (zero_dS || dd > g_hi) ? zero4 : gv[k];
+            const f32x4 sx = (zero_S || dd > s_hi) ? zero4 : sv[k];
+            if (d + k < d1) {
+              sn += gc * sc;
+              sp += gc * sm;
+              sq += gc * sx;
+              const f32x4 dprev = anoop * gc + apush * gn + apop * gm;
+              st4(dSout + (size_t)(d + k) * rstr + cofs, dprev);
+              if (d + k == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const float dv = apush[j] * gc[j];
+                  dxl[(4 * bq + j) * XP + 3 + w] = dv * (1.0f - pv[j] * pv[j]);
+                }
+              }
+              gm = gc; gc = gn; sm = sc; sc = sx;
             }
           }
-          gm = gc; gc = gn; sm = sc; sc = sx;
         }
 #undef LD_S
 #undef LD_G
@@ -298,7 +316,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
           const int row = row0 + bb;
           const float R = (row < B) ? a.reward[row] : 0.0f;
           const int y = (row < B) ? (int)a.tokens[(size_t)p * B + row] : 0;
-          const float pr = a.PR[(((size_t)(p - 1) * G + g) * a.VP + v) * 16 + bb];
+          const float pr = pmg_ld1h<4>(a.PR + (((size_t)(p - 1) * G + g) * a.VP + v) * 16 + bb);
           val = sc * R * (pr - ((v == y) ? 1.0f : 0.0f));
         }
         dxl[bb * XP + 3 + W + v] = val;
@@ -326,7 +344,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
       float* dxg = a.DX + ((size_t)p * G + g) * NXT * 256;
       for (int idx = tid; idx < NXT * 256; idx += PMG_THREADS) {
         const int bb = idx & 15, nrow = idx >> 4;
-        dxg[idx] = dxl[bb * XP + nrow];
+        pmg_st1h<8>(dxg + idx, dxl[bb * XP + nrow]);
       }
       f32x4 acc[UPW];
 #pragma unroll

@@ -18,8 +18,9 @@
 #define PMG_XTP 72      // LDS pitch of the stack-top tile (64 + 8: conflict-free ds_read_b128)
 #define PMG_CHUNK 128   // hidden units per backward chunk (PMG_WAVES * 16)
 #define PMG_CP 520      // LDS pitch of a backward chunk row (4*128 + 8)
-#define PMG_SBLK 26     // stack rows a thread updates per register burst (forward)
-#define PMG_SBLKB 13    // same for the backward (two arrays in flight)
+#ifndef PMG_SBLKB
+#define PMG_SBLKB 5     // stack rows per load burst of the backward (2 loads per row in flight)
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -120,6 +121,29 @@ __device__ __forceinline__ float4 pmg_bload(__amdgpu_buffer_rsrc_t r, unsigned v
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t pmg_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+// History streams (written once by the forward, read once by the backward / weight-gradient
+// GEMM much later) can be issued non-temporal so that they do not evict the packed weights from
+// the 4 MB L2s.  PMG_NT is a compile-time mask choosing which streams are (tuning knob).
+#ifndef PMG_NT
+#define PMG_NT 12
+#endif
+template <int BIT> __device__ __forceinline__ void pmg_st4h(float* p, const f32x4 v) {
+  if (PMG_NT & BIT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  else *reinterpret_cast<f32x4*>(p) = v;
+}
+template <int BIT> __device__ __forceinline__ void pmg_st1h(float* p, const float v) {
+  if (PMG_NT & BIT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+template <int BIT> __device__ __forceinline__ f32x4 pmg_ld4h(const float* p) {
+  if (PMG_NT & BIT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return *reinterpret_cast<const f32x4*>(p);
+}
+template <int BIT> __device__ __forceinline__ float pmg_ld1h(const float* p) {
+  if (PMG_NT & BIT) return __builtin_nontemporal_load(p);
+  return *p;
 }
 
 __device__ __forceinline__ float pmg_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
           }
           float* pr = a.PR + ((size_t)(i - 1) * G + g) * a.VP * 16;
           const float inv = 1.0f / total;
-          for (int v = v0; v < v1; ++v) pr[v * 16 + bb] = expf(lg[v] - m) * inv;
+          for (int v = v0; v < v1; ++v) pmg_st1h<1>(pr + v * 16 + bb, expf(lg[v] - m) * inv);
           if (s == 0) misc[bb] = y;
         } else if (a.logits_out != nullptr && rowok) {
           for (int v = v0; v < v1; ++v) a.logits_out[(size_t)row * V + v] = lg[v];
@@ -410,7 +410,8 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
       r0 = r1; r1 = r2; r2 = ldv;
       if (act) {
         const f32x4 nw = anoop * s_cur + apush * s_prev + apop * nxt;
-        st4(st_Snew + (size_t)d * W * 16, nw);
+        if (keep) pmg_st4h<2>(st_Snew + (size_t)d * W * 16, nw);
+        else st4(st_Snew + (size_t)d * W * 16, nw);
         if (d == 0) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) xtop[(4 * st_bq + j) * PMG_XTP + st_w] = nw[j];
@@ -470,10 +471,10 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
         st4(hp_ptr, hn);
         if (keep) {
           float* gp = a.GT[0] + ((((size_t)i * G + g) * UT + ug) * 4) * 256 + lane * 4;
-          st4(gp, r); st4(gp + 256, z); st4(gp + 512, n); st4(gp + 768, vh);
+          pmg_st4h<1>(gp, r); pmg_st4h<1>(gp + 256, z); pmg_st4h<1>(gp + 512, n); pmg_st4h<1>(gp + 768, vh);
           float* hh = a.HH[0] + (((size_t)(i + 1) * G + g) * H + j0) * 16 + b;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) hh[j * 16] = hn[j];
+          for (int j = 0; j < 4; ++j) pmg_st1h<1>(hh + j * 16, hn[j]);
         }
       }
     }
@@ -509,10 +510,10 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
         st4(hp_ptr, hn);
         if (keep) {
           float* gp = a.GT[l] + ((((size_t)i * G + g) * UT + ug) * 4) * 256 + lane * 4;
-          st4(gp, r); st4(gp + 256, z); st4(gp + 512, n); st4(gp + 768, ah[u]);
+          pmg_st4h<1>(gp, r); pmg_st4h<1>(gp + 256, z); pmg_st4h<1>(gp + 512, n); pmg_st4h<1>(gp + 768, ah[u]);
           float* hh = a.HH[l] + (((size_t)(i + 1) * G + g) * H + j0) * 16 + b;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) hh[j * 16] = hn[j];
+          for (int j = 0; j < 4; ++j) pmg_st1h<1>(hh + j * 16, hn[j]);
         }
       }
       __syncthreads();
