@@ -43,42 +43,38 @@ def uniform(seed: int, seq: int, step: int) -> np.float32:
 
 
 def sample_row(logits, temperature, u):
-    """Inverse-CDF draw over 4 contiguous chunks, fp32, same operation order as the kernel.
+    """Inverse-CDF draw, fp32, same operation order as the kernel (pmg_fwd.hip, "consume logits"):
+    entries are taken in slots of 32 (one per lane), the running CDF of a slot is a 32-lane
+    Hillis-Steele inclusive scan added to the carry of the previous slots, the draw is the first
+    entry whose CDF exceeds u * total.
 
     Returns (choice, margin, probs): margin = distance of u to the nearest CDF boundary
     (fp64), used by the tests to excuse boundary-rounding differences."""
     f = np.float32
     logits = np.asarray(logits, dtype=np.float32)
     V = logits.shape[0]
-    CH = (V + 3) // 4
     x = (logits / f(temperature)).astype(np.float32)
     m = x.max()
     e = np.exp((x - m).astype(np.float32)).astype(np.float32)
-    cs, rng = [], []
-    for s in range(4):
-        v0 = s * CH
-        v1 = min(V, v0 + CH)
-        acc = f(0.0)
-        for v in range(v0, max(v0, v1)):
-            acc = f(acc + e[v])
-        cs.append(acc)
-        rng.append((v0, v1))
-    total = f(f(f(cs[0] + cs[1]) + cs[2]) + cs[3])
-    target = f(f(u) * total)
-    pre = [f(0.0), cs[0], f(cs[0] + cs[1]), f(f(cs[0] + cs[1]) + cs[2])]
-    choice = V - 1
-    for s in range(4):
-        v0, v1 = rng[s]
-        if v0 < v1 and target < f(pre[s] + cs[s]):
-            run = pre[s]
-            choice = v1 - 1
-            for v in range(v0, v1):
-                run = f(run + e[v])
-                if target < run:
-                    choice = v
-                    break
-            break
+    cdf = np.zeros(V, dtype=np.float32)
+    carry = f(0.0)
+    for k in range((V + 31) // 32):
+        seg = np.zeros(32, dtype=np.float32)
+        n = min(32, V - 32 * k)
+        seg[:n] = e[32 * k:32 * k + n]
+        o = 1
+        while o <= 16:
+            nxt = seg.copy()
+            nxt[o:] = (seg[o:] + seg[:-o]).astype(np.float32)
+            seg = nxt
+            o *= 2
+        c = (carry + seg).astype(np.float32)
+        cdf[32 * k:32 * k + n] = c[:n]
+        carry = c[31]
+    target = f(f(u) * carry)
+    hit = np.nonzero(target < cdf)[0]
+    choice = int(hit[0]) if hit.size else V - 1
     e64 = e.astype(np.float64)
-    cdf = np.cumsum(e64) / e64.sum()
-    margin = float(np.min(np.abs(cdf - float(u))))
+    cdf64 = np.cumsum(e64) / e64.sum()
+    margin = float(np.min(np.abs(cdf64 - float(u))))
     return int(choice), margin, e64 / e64.sum()

@@ -124,6 +124,11 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
   __syncthreads();
 
   int par = 0;  // chunk buffer parity, alternates on every chunk
+  // PMG_DEBUG bit 0x8000: per-phase cycle counters of workgroup 0, printed at the end
+  const bool prof = (dbg & 0x8000) != 0;
+  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#define PMG_TICK(k) if (prof) { const long long tn_ = (long long)__builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; }
 
   // p == N is the virtual step that only injects dlogits_{N-1}
   for (int p = N; p >= 0; --p) {
@@ -180,7 +185,9 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
             pmg_st1h<8>(dg_base + ((size_t)(2 * H + j0 + j)) * 16 + b, dn_pre[j]);
             pmg_st1h<8>(dg_base + ((size_t)(3 * H + j0 + j)) * 16 + b, dghn[j]);
           }
+          PMG_TICK(0)
           __syncthreads();
+          PMG_TICK(1)
           // ---- products over this chunk's 3*128 reduction rows
           const float* xb = cb + (size_t)par * 16 * PMG_CP + b * PMG_CP + 4 * q;
           {
@@ -195,6 +202,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
             if (!(dbg & 0x800)) gemm_chunk<1>(acc_top, wrs, voff, so, KG3 * 1024u, xb, 0, 1, 2);
           }
           par ^= 1;
+          PMG_TICK(2)
         }
 #pragma unroll
         for (int u = 0; u < UPW; ++u) {
@@ -204,6 +212,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
         if (l == 0 && wave < PMG_KS / 16) st4(dtl + b * PMG_XTP + 16 * wave + 4 * q, acc_top[0]);
       }
       __syncthreads();  // dtop visible; chunk buffers free
+      PMG_TICK(3)
     }
 
     // ------------------------------------------------------------ stack backward
@@ -306,6 +315,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
         for (int j = 0; j < 4; ++j) { rp[j] = sp[j]; rp[4 + j] = sq[j]; rp[8 + j] = sn[j]; }
       }
     }
+    PMG_TICK(4)
     // ------------------------------------------------------------ dlogits_{p-1}, loss
     {
       const float sc = a.scale;
@@ -339,6 +349,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
       dxl[tid * XP + 2] = a2 * (dno - s);
     }
     __syncthreads();
+    PMG_TICK(5)
     // ------------------------------------------------------------ DX slab + extras product
     {
       float* dxg = a.DX + ((size_t)p * G + g) * NXT * 256;
@@ -354,8 +365,13 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
 #pragma unroll
       for (int u = 0; u < UPW; ++u) st4(dhc + ((size_t)((L - 1) * UT + wave * UPW + u)) * 256 + lane * 4, acc[u]);
     }
+    PMG_TICK(6)
     __syncthreads();  // dxl / dtl / red reusable
+    PMG_TICK(7)
   }
+  if (prof && g == 0 && (tid & 63) == 0)
+    printf("bwd wave %d cycles(100MHz): cell %lld sync %lld gemm %lld sync2 %lld stack %lld dlogits+ctrl %lld extras %lld sync3 %lld\n", wave,
+           tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7]);
 
   // ---------------------------------------------------------------- outputs
   for (int l = 0; l < L; ++l)

@@ -217,7 +217,9 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     }
   }
 
-  // sampling state (meaningful in wave 0 only)
+  // logits are consumed by every wave: rows 2*wave and 2*wave+1, 32 lanes per row
+  const int cs_bb = 2 * wave + (lane >> 5);
+  // sampling state of row cs_bb (identical in the 32 lanes of the row)
   bool finished = false;
   int mylen = N;
 
@@ -241,6 +243,12 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
   }
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   NoSide no_side;
+
+  // PMG_DEBUG bit 0x8000: per-phase cycle counters of workgroup 0, printed at the end
+  const bool prof = (dbg & 0x8000) != 0;
+  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#define PMG_TICK(k) if (prof) { const long long tn_ = (long long)__builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; }
 
   for (int i = 0;; ++i) {
     // ------------------------------------------------------------ stack: first rows requested early
@@ -273,6 +281,10 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
       if (st_d0 + 3 <= st_old_hi) r2 = ld4(st_Sold + (size_t)(st_d0 + 3) * W * 16);
     }
 
+    // target token of step i-1 (teacher): requested here, used after the extras GEMM
+    int cs_y = 0;
+    if (teacher && i >= 1 && row0 + cs_bb < B) cs_y = (int)a.tok_in[(size_t)i * B + row0 + cs_bb];
+
     // ------------------------------------------------------------ extras GEMM
     if (!(dbg & 0x200)) {
       const float* xrow = h_lds + (size_t)((L - 1) * 16 + b) * HP + 4 * q;
@@ -282,50 +294,50 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
         st4(&xex[b * XP + 16 * xt + 4 * q], acc);
       }
     }
+    PMG_TICK(0)
     __syncthreads();  // B1
+    PMG_TICK(1)
 
     // ------------------------------------------------------------ consume logits of step i-1
-    if (i >= 1 && wave == 0 && !(dbg & 0x2000)) {
-      const int bb = lane >> 2, s = lane & 3;
+    // Every wave takes two rows; a row's V logits are spread over 32 lanes (entry v sits in lane
+    // v&31, slot v>>5), so max / sum / argmax are 5-step butterflies and the sampler's CDF is a
+    // 32-lane inclusive scan per slot (oracle twin: oracle/philox.py sample_row).
+    if (i >= 1 && !(dbg & 0x2000)) {
+      const int bb = cs_bb, l5 = lane & 31;
       const int row = row0 + bb;
       const bool rowok = row < B;
       const float* lg = xex + bb * XP + 3 + W;
-      const int CH = (V + 3) >> 2;
-      const int v0 = s * CH;
-      const int v1 = (v0 + CH < V) ? v0 + CH : V;
-      const int lbase = lane & ~3;
       if (!decode) {
         float m = -INFINITY;
-        for (int v = v0; v < v1; ++v) m = fmaxf(m, lg[v]);
-        m = fmaxf(m, __shfl_xor(m, 1));
-        m = fmaxf(m, __shfl_xor(m, 2));
-        float cs = 0.0f;
-        for (int v = v0; v < v1; ++v) cs += expf(lg[v] - m);
-        const float c0 = __shfl(cs, lbase), c1 = __shfl(cs, lbase + 1), c2 = __shfl(cs, lbase + 2),
-                    c3 = __shfl(cs, lbase + 3);
-        const float total = ((c0 + c1) + c2) + c3;
+        for (int v = l5; v < V; v += 32) m = fmaxf(m, lg[v]);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float total = 0.0f;
+        for (int v = l5; v < V; v += 32) total += __expf(lg[v] - m);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) total += __shfl_xor(total, o);
         if (teacher) {
-          const int y = rowok ? (int)a.tok_in[(size_t)i * B + row] : 0;
-          if (y >= v0 && y < v1) {
-            const float lp = (lg[y] - m) - logf(total);
+          const int y = cs_y;
+          if ((y & 31) == l5) {
+            const float lp = (lg[y] - m) - __logf(total);
             a.LP[((size_t)(i - 1) * G + g) * 16 + bb] = lp;
             if (rowok) a.logp_out[(size_t)(i - 1) * B + row] = lp;
+            misc[bb] = y;
           }
           float* pr = a.PR + ((size_t)(i - 1) * G + g) * a.VP * 16;
-          const float inv = 1.0f / total;
-          for (int v = v0; v < v1; ++v) pmg_st1h<1>(pr + v * 16 + bb, expf(lg[v] - m) * inv);
-          if (s == 0) misc[bb] = y;
+          const float inv = __builtin_amdgcn_rcpf(total);
+          for (int v = l5; v < V; v += 32) pmg_st1h<1>(pr + v * 16 + bb, __expf(lg[v] - m) * inv);
         } else if (a.logits_out != nullptr && rowok) {
-          for (int v = v0; v < v1; ++v) a.logits_out[(size_t)row * V + v] = lg[v];
+          for (int v = l5; v < V; v += 32) a.logits_out[(size_t)row * V + v] = lg[v];
         }
       } else {
         const bool greedy = !(a.temperature > 0.0f);
         int tok;
         if (greedy) {
           float bv = -INFINITY; int bi = 0x7fffffff;
-          for (int v = v0; v < v1; ++v) { const float x = lg[v]; if (x > bv) { bv = x; bi = v; } }
+          for (int v = l5; v < V; v += 32) { const float x = lg[v]; if (x > bv) { bv = x; bi = v; } }
 #pragma unroll
-          for (int o = 1; o <= 2; o <<= 1) {
+          for (int o = 16; o >= 1; o >>= 1) {
             const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
           }
@@ -333,39 +345,49 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
         } else {
           const float T = a.temperature;
           float m = -INFINITY;
-          for (int v = v0; v < v1; ++v) m = fmaxf(m, lg[v] / T);
-          m = fmaxf(m, __shfl_xor(m, 1));
-          m = fmaxf(m, __shfl_xor(m, 2));
-          float cs = 0.0f;
-          for (int v = v0; v < v1; ++v) cs += expf(lg[v] / T - m);
-          const float c0 = __shfl(cs, lbase), c1 = __shfl(cs, lbase + 1), c2 = __shfl(cs, lbase + 2),
-                      c3 = __shfl(cs, lbase + 3);
-          const float total = ((c0 + c1) + c2) + c3;
-          const float u = pmg_uniform(a.seed, (uint64_t)(a.seq_base + row), a.offset + (uint64_t)(i - 1));
-          const float target = u * total;
-          const float pre = (s == 0) ? 0.0f : (s == 1) ? c0 : (s == 2) ? (c0 + c1) : ((c0 + c1) + c2);
-          const bool cond = (v0 < v1) && (target < pre + cs);
-          const unsigned long long bal = __ballot(cond);
-          const unsigned m4 = (unsigned)((bal >> lbase) & 0xFull);
-          const int sel = m4 ? (__ffs(m4) - 1) : -1;
-          int cand = V - 1;
-          if (sel == s) {
-            cand = v1 - 1;
-            float run = pre;
-            for (int v = v0; v < v1; ++v) {
-              run += expf(lg[v] / T - m);
-              if (target < run) { cand = v; break; }
+          for (int v = l5; v < V; v += 32) m = fmaxf(m, lg[v] / T);
+#pragma unroll
+          for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+          // running CDF: slot k holds entries 32k..32k+31, one per lane
+          float cdf[8];
+          float carry = 0.0f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            cdf[k] = 0.0f;
+            if (32 * k < V) {
+              const int v = 32 * k + l5;
+              float e = (v < V) ? __expf(lg[v] / T - m) : 0.0f;
+#pragma unroll
+              for (int o = 1; o <= 16; o <<= 1) {
+                const float t = __shfl_up(e, o, 32);
+                if (l5 >= o) e += t;
+              }
+              cdf[k] = carry + e;
+              carry = __shfl(cdf[k], 31, 32);
             }
           }
-          tok = __shfl(cand, lbase + (sel < 0 ? 0 : sel));
+          const float u = pmg_uniform(a.seed, (uint64_t)(a.seq_base + row), a.offset + (uint64_t)(i - 1));
+          const float target = u * carry;
+          tok = -1;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (32 * k < V) {
+              const int v = 32 * k + l5;
+              const unsigned long long bal = __ballot((v < V) && (target < cdf[k]));
+              const unsigned mk = (unsigned)(bal >> (lane & 32));
+              if (tok < 0 && mk) tok = 32 * k + (__ffs(mk) - 1);
+            }
+          }
+          if (tok < 0) tok = V - 1;
         }
-        if (rowok && s == 0) a.tok_out[(size_t)row * N + (i - 1)] = tok;
+        if (rowok && l5 == 0) a.tok_out[(size_t)row * N + (i - 1)] = tok;
         if (!finished && tok == a.stop_tok) { finished = true; mylen = i - 1; }
-        if (s == 0) misc[bb] = tok;
+        if (l5 == 0) misc[bb] = tok;
         const bool alld = __all(finished || !rowok);
-        if (lane == 0) misc[16] = (alld && !(a.flags & PMG_FLAG_NO_EARLY_EXIT)) ? 1 : 0;
+        if (lane == 0) misc[16 + wave] = (alld && !(a.flags & PMG_FLAG_NO_EARLY_EXIT)) ? 1 : 0;
       }
     }
+    PMG_TICK(2)
     if (i == N) break;
 
     // ------------------------------------------------------------ stack update, streamed under the gh GEMM
@@ -434,9 +456,11 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     }
     if (!(dbg & 0x400)) gemm3<UPW, TPP>(ar, az, ah, wrs, voff, a.oWHH[0], KGH, h_lds + (size_t)b * HP + 4 * q, wave, stack_row);
     while (sj < st_dch) stack_row();  // rows the GEMM loop did not reach
+    PMG_TICK(3)
     __syncthreads();  // B2: stack top + token visible; every read of h_lds[0] (old) is done
 
-    if (decode && misc[16]) {
+    PMG_TICK(4)
+    if (decode && (misc[16] & misc[17] & misc[18] & misc[19] & misc[20] & misc[21] & misc[22] & misc[23])) {
       // every row of this group has emitted stop_tok: fill the tail and leave
       for (int idx = tid; idx < 16 * (N - i); idx += PMG_THREADS) {
         const int bb = idx / (N - i), t = i + (idx - bb * (N - i));
@@ -478,7 +502,9 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
         }
       }
     }
+    PMG_TICK(5)
     __syncthreads();  // B3
+    PMG_TICK(6)
 
     // ------------------------------------------------------------ layers 1..L-1
     for (int l = 1; l < L; ++l) {
@@ -520,11 +546,11 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     }
   }
 
+  if (prof && g == 0 && lane == 0)
+    printf("fwd wave %d cycles: extras %lld syncB1 %lld logits %lld gh+stack %lld syncB2 %lld top+gates %lld syncB3 %lld\n", wave,
+           tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6]);
   // ---------------------------------------------------------------- epilogue
-  if (decode && wave == 0) {
-    const int bb = lane >> 2, s = lane & 3;
-    if (s == 0 && row0 + bb < B) a.len_out[row0 + bb] = mylen;
-  }
+  if (decode && (lane & 31) == 0 && row0 + cs_bb < B) a.len_out[row0 + cs_bb] = mylen;
   if (a.h_out != nullptr) {
     for (int idx = tid; idx < L * 16 * H; idx += PMG_THREADS) {
       const int l = idx / (16 * H);

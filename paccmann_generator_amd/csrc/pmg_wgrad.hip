@@ -23,10 +23,15 @@
 #define WG_TM 128
 #define WG_THREADS 256
 #define WG_MAXJOBS (2 + 2 * PMG_MAX_LAYERS + 1)
+#define WG_PLAIN 0
+#define WG_ONEHOT 1
+#define WG_MIXED 2
 
 struct WJob {
   const float* A;   // slabs [P][G][a_rows][16]
-  const float* B;   // slabs [P(+shift)][G][b_rows][16]  (NULL: one-hot of tokens)
+  const float* B;   // slabs [P(+shift)][G][b_rows][16]  (unused when mode == WG_ONEHOT)
+  int mode;         // WG_PLAIN, WG_ONEHOT (B = one-hot of the tokens) or WG_MIXED (columns 0..63 from B,
+                    // columns 64..127 one-hot of the tokens: the stack-top and embedding-table jobs share A)
   int a_rows;       // rows of one A slab
   int skip_mid;     // 1: job row r >= 2H maps to slab row r + H (dgh: skip the dn piece)
   int b_rows;       // rows of one B slab
@@ -61,8 +66,9 @@ namespace {
 // the slab and their (garbage) results are simply never read back.  Operands stream
 // through buffer resources (SGPR descriptor + one lane-constant VGPR offset + a uniform
 // byte offset per fragment); two register sets keep the next slab in flight.
-template <int MI, int NJ, int WR, int WC, bool ONEHOT>
+template <int MI, int NJ, int WR, int WC, int MODE>
 __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArgs a) {
+  static_assert(MODE != WG_MIXED || (WC == 2 && NJ == 4), "mixed tiles: one wave column per half");
   constexpr int TN = 16 * NJ * WC;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArg
   // tiles of this variant
   int ntiles = 0;
   for (int k = 0; k < a.njobs; ++k)
-    if (a.jobs[k].tn == TN && (a.jobs[k].B == nullptr) == ONEHOT) ntiles += a.jobs[k].row_tiles * a.jobs[k].col_tiles;
+    if (a.jobs[k].tn == TN && a.jobs[k].mode == MODE) ntiles += a.jobs[k].row_tiles * a.jobs[k].col_tiles;
   // XCD-aware remap: blocks b and b+8 share an XCD; give each XCD a contiguous run of
   // virtual ids so that the tiles of one split (same slabs) meet in one L2.
   const int nblk = gridDim.x;  // multiple of 8
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArg
   int t = v - s * ntiles;
   int ji = 0;
   for (int k = 0; k < a.njobs; ++k) {
-    if (a.jobs[k].tn == TN && (a.jobs[k].B == nullptr) == ONEHOT) {
+    if (a.jobs[k].tn == TN && a.jobs[k].mode == MODE) {
       const int nt = a.jobs[k].row_tiles * a.jobs[k].col_tiles;
       if (t < nt) { ji = k; break; }
       t -= nt;
@@ -114,14 +120,18 @@ __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArg
   for (int j = 0; j < NJ; ++j) {
     int cc = c0 + 16 * j;
     if (cc >= jb.cols) cc = 0;
+    if (MODE == WG_MIXED) cc &= 63;  // the one-hot half never loads; keep its offsets in range
     brow[j] = (unsigned)cc * 64u;
   }
+  // one-hot columns: token id that column n16 of fragment j stands for
+  const bool onehot = (MODE == WG_ONEHOT) || (MODE == WG_MIXED && wc == 1);
+  const int oh0 = (MODE == WG_MIXED) ? 0 : c0;
   const unsigned voff = (unsigned)(n16 * 16 + 4 * q) * 4u;
   const unsigned astr = (unsigned)jb.a_rows * 64u, bstr = (unsigned)jb.b_rows * 64u;
   const int nsafe = ns > 0 ? ns : 0;
   const __amdgpu_buffer_rsrc_t ars = pmg_rsrc(jb.A + (size_t)sl0 * jb.a_rows * 16, (unsigned)nsafe * astr);
   const __amdgpu_buffer_rsrc_t brs =
-      ONEHOT ? ars : pmg_rsrc(jb.B + ((size_t)sl0 + (size_t)jb.b_pshift * G) * jb.b_rows * 16, (unsigned)nsafe * bstr);
+      (MODE == WG_ONEHOT) ? ars : pmg_rsrc(jb.B + ((size_t)sl0 + (size_t)jb.b_pshift * G) * jb.b_rows * 16, (unsigned)nsafe * bstr);
 
   f32x4 acc[MI][NJ];
 #pragma unroll
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArg
 #define WG_LOAD_A(dst, k) \
   _Pragma("unroll") for (int i = 0; i < MI; ++i) dst[i] = pmg_bload(ars, voff, (unsigned)(k) * astr + arow[i]);
   auto load_b = [&](int k, float4 (&fb)[NJ]) {
-    if (!ONEHOT) {
+    if (!onehot) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) fb[j] = pmg_bload(brs, voff, (unsigned)k * bstr + brow[j]);
     } else {
@@ -151,7 +161,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArg
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int col = c0 + 16 * j + n16;
+        const int col = oh0 + 16 * j + n16;
         fb[j] = make_float4(tk[0] == col ? 1.f : 0.f, tk[1] == col ? 1.f : 0.f, tk[2] == col ? 1.f : 0.f,
                             tk[3] == col ? 1.f : 0.f);
       }
@@ -248,6 +258,7 @@ __global__ void pmg_wgrad_reduce_kernel(const WgradArgs a) {
 
 struct FinArgs {
   int H, E, W, V, L, NX, NXT, VP, G, pad_idx, accumulate;
+  int ld_tab, ld_is;  // row pitch of the dGTAB block and of the dW_ih0[:, E:] block inside dense
   const float* dense;
   size_t c_hh[PMG_MAX_LAYERS], c_ih[PMG_MAX_LAYERS], c_tab, c_x;  // c_ih[0] = IS job
   size_t rs_hh[PMG_MAX_LAYERS], rs_gi[PMG_MAX_LAYERS], rs_x;       // absolute offsets in dense
@@ -270,25 +281,16 @@ __global__ void pmg_finalize_kernel(const FinArgs a) {
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (size_t)gridDim.x * blockDim.x) {
     size_t r = idx;
-    if (r < n_emb) {
-      const int v = (int)(r / E), e = (int)(r % E);
-      float s = 0.0f;
-      if (v != a.pad_idx) {
-        const float* tab = a.dense + a.c_tab;  // [3H][VP]
-        for (int n = 0; n < 3 * H; ++n) s = fmaf(tab[(size_t)n * a.VP + v], a.w_ih0[(size_t)n * (E + W) + e], s);
-      }
-      put(a.g.embedding + r, s, a.accumulate);
-      continue;
-    }
+    if (r < n_emb) continue;  // embedding gradient: pmg_embgrad_kernel
     r -= n_emb;
     if (r < n_wih0) {
       const int n = (int)(r / (E + W)), e = (int)(r % (E + W));
       float s = 0.0f;
       if (e < E) {
-        const float* tab = a.dense + a.c_tab + (size_t)n * a.VP;
+        const float* tab = a.dense + a.c_tab + (size_t)n * a.ld_tab;
         for (int v = 0; v < V; ++v) s = fmaf(tab[v], a.emb[(size_t)v * E + e], s);
       } else {
-        s = a.dense[a.c_ih[0] + (size_t)n * PMG_KS + (e - E)];
+        s = a.dense[a.c_ih[0] + (size_t)n * a.ld_is + (e - E)];
       }
       put(a.g.w_ih[0] + r, s, a.accumulate);
       continue;
@@ -339,6 +341,28 @@ __global__ void pmg_finalize_kernel(const FinArgs a) {
   }
 }
 
+// d embedding[v][e] = sum_n dGTAB[n][v] * W_ih0[n][e]  (n over the 3H gate rows).  One block per
+// (token v, 64 columns e); 16 segments of the reduction per block, combined in a fixed order.
+__global__ __launch_bounds__(1024) void pmg_embgrad_kernel(const FinArgs a) {
+  __shared__ float part[16][64];
+  const int v = blockIdx.x, e = blockIdx.y * 64 + (threadIdx.x & 63), seg = threadIdx.x >> 6;
+  const int K = 3 * a.H, per = (K + 15) / 16;
+  const int n0 = seg * per, n1 = (n0 + per < K) ? n0 + per : K;
+  float s = 0.0f;
+  if (e < a.E && v != a.pad_idx) {
+    const float* tab = a.dense + a.c_tab + v;
+    const float* wi = a.w_ih0 + e;
+    for (int n = n0; n < n1; ++n) s = fmaf(tab[(size_t)n * a.ld_tab], wi[(size_t)n * (a.E + a.W)], s);
+  }
+  part[seg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (seg == 0 && e < a.E) {
+    float t = 0.0f;
+    for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x];
+    put(a.g.embedding + (size_t)v * a.E + e, t, a.accumulate);
+  }
+}
+
 struct JobPlan {
   WgradArgs w;
   FinArgs f;
@@ -366,8 +390,9 @@ void build_plan(const PmgDims& d, JobPlan* P) {
   const int H = d.H, N = d.T - 1;
   int nj = 0, tile_w = 0, tile_n = 0, rs = 0;
   size_t coff = 0, ptoff = 0;
-  auto add = [&](int rows, int cols, int a_rows, int skip_mid, int b_rows, int b_pshift, int Psl) -> WJob& {
+  auto add = [&](int rows, int cols, int a_rows, int skip_mid, int b_rows, int b_pshift, int Psl, int mode) -> WJob& {
     WJob& j = w.jobs[nj++];
+    j.mode = mode;
     j.rows = rows; j.cols = cols; j.a_rows = a_rows; j.skip_mid = skip_mid; j.b_rows = b_rows;
     j.b_pshift = b_pshift; j.P = Psl;
     j.tn = (cols <= 64) ? 64 : 128;
@@ -380,13 +405,23 @@ void build_plan(const PmgDims& d, JobPlan* P) {
     return j;
   };
   // job order is fixed; pointers are filled by the caller
-  for (int l = 0; l < d.L; ++l) { WJob& j = add(3 * H, H, 4 * H, 1, H, 0, N); f.c_hh[l] = j.c_off; f.rs_hh[l] = j.rs0; }
+  for (int l = 0; l < d.L; ++l) { WJob& j = add(3 * H, H, 4 * H, 1, H, 0, N, WG_PLAIN); f.c_hh[l] = j.c_off; f.rs_hh[l] = j.rs0; }
+  // layer 0: the stack-top columns of W_ih and the per-token gate table share their A operand
+  // ([dr|dz|dn]); with a vocabulary of at most 64 they are the two halves of one 128-wide tile column
+  const bool mixed = d.VP <= 64;
   for (int l = 0; l < d.L; ++l) {
-    WJob& j = (l == 0) ? add(3 * H, PMG_KS, 4 * H, 0, PMG_KS, 0, N) : add(3 * H, H, 4 * H, 0, H, 1, N);
+    WJob& j = (l == 0) ? (mixed ? add(3 * H, 128, 4 * H, 0, PMG_KS, 0, N, WG_MIXED)
+                                : add(3 * H, PMG_KS, 4 * H, 0, PMG_KS, 0, N, WG_PLAIN))
+                       : add(3 * H, H, 4 * H, 0, H, 1, N, WG_PLAIN);
     f.c_ih[l] = j.c_off; f.rs_gi[l] = j.rs0;
   }
-  { WJob& j = add(3 * H, d.VP, 4 * H, 0, 0, 0, N); f.c_tab = j.c_off; }
-  { WJob& j = add(d.NXT * 16, H, d.NXT * 16, 0, H, 0, N + 1); f.c_x = j.c_off; f.rs_x = j.rs0; }
+  if (mixed) {
+    f.c_tab = f.c_ih[0] + 64; f.ld_tab = 128; f.ld_is = 128;
+  } else {
+    WJob& j = add(3 * H, d.VP, 4 * H, 0, 0, 0, N, WG_ONEHOT);
+    f.c_tab = j.c_off; f.ld_tab = d.VP; f.ld_is = PMG_KS;
+  }
+  { WJob& j = add(d.NXT * 16, H, d.NXT * 16, 0, H, 0, N + 1, WG_PLAIN); f.c_x = j.c_off; f.rs_x = j.rs0; }
   w.njobs = nj; w.tiles_wide = tile_w; w.tiles_narrow = tile_n; w.total_rs = rs;
   w.S = choose_splits(d, tile_w + tile_n);
   w.split_stride = ptoff;
@@ -430,14 +465,14 @@ hipError_t pmg_run_wgrad(const PmgDims& d, const PmgLayout& lay, float* ws, cons
     w.jobs[k].B = (l == 0) ? ws + lay.TP : ws + lay.HH[l - 1];
     ++k;
   }
-  w.jobs[k].A = ws + lay.DG[0]; w.jobs[k].B = nullptr; ++k;
+  if (w.jobs[k].mode == WG_ONEHOT) { w.jobs[k].A = ws + lay.DG[0]; w.jobs[k].B = ws + lay.DG[0]; ++k; }
   w.jobs[k].A = ws + lay.DX; w.jobs[k].B = ws + lay.HH[d.L - 1]; ++k;
 
   hipError_t e = hipSuccess;
   {
-    int nt[2][2] = {{0, 0}, {0, 0}};  // [wide][onehot]
+    int nt[2][3] = {{0, 0, 0}, {0, 0, 0}};  // [wide][mode]
     for (int j = 0; j < w.njobs; ++j)
-      nt[w.jobs[j].tn == 128][w.jobs[j].B == nullptr] += w.jobs[j].row_tiles * w.jobs[j].col_tiles;
+      nt[w.jobs[j].tn == 128][w.jobs[j].mode] += w.jobs[j].row_tiles * w.jobs[j].col_tiles;
 #define PMG_WG_LAUNCH(cnt, ...)                                                              \
   if ((cnt) > 0) {                                                                           \
     const int nb = (((cnt) * w.S + 7) / 8) * 8;                                              \
@@ -445,10 +480,11 @@ hipError_t pmg_run_wgrad(const PmgDims& d, const PmgLayout& lay, float* ws, cons
     e = hipGetLastError();                                                                   \
     if (e != hipSuccess) return e;                                                           \
   }
-    PMG_WG_LAUNCH(nt[1][0], 4, 4, 2, 2, false)
-    PMG_WG_LAUNCH(nt[1][1], 4, 4, 2, 2, true)
-    PMG_WG_LAUNCH(nt[0][0], 2, 4, 4, 1, false)
-    PMG_WG_LAUNCH(nt[0][1], 2, 4, 4, 1, true)
+    PMG_WG_LAUNCH(nt[1][WG_PLAIN], 4, 4, 2, 2, WG_PLAIN)
+    PMG_WG_LAUNCH(nt[1][WG_MIXED], 4, 4, 2, 2, WG_MIXED)
+    PMG_WG_LAUNCH(nt[1][WG_ONEHOT], 4, 4, 2, 2, WG_ONEHOT)
+    PMG_WG_LAUNCH(nt[0][WG_PLAIN], 2, 4, 4, 1, WG_PLAIN)
+    PMG_WG_LAUNCH(nt[0][WG_ONEHOT], 2, 4, 4, 1, WG_ONEHOT)
 #undef PMG_WG_LAUNCH
   }
   {
@@ -474,6 +510,9 @@ hipError_t pmg_run_wgrad(const PmgDims& d, const PmgLayout& lay, float* ws, cons
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pmg_finalize_kernel, dim3(blocks), dim3(256), 0, st, f);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(pmg_embgrad_kernel, dim3(d.V, (d.E + 63) / 64), dim3(1024), 0, st, f);
     e = hipGetLastError();
   }
   return e;

@@ -46,6 +46,14 @@ def test_train_parity_ragged_batch(gpu):
     P.check_train(dict(P.TINY, pad_index=None), B=33, T=6, tol=TOL)
 
 
+def test_train_parity_large_vocab(gpu):
+    """V > 64: the embedding-table gradient runs as its own one-hot GEMM job."""
+    P.check_train(dict(P.TINY, vocab_size=97), B=21, T=8, tol=TOL)
+    P.check_greedy(dict(P.TINY, vocab_size=97), 18, 9)
+    r = P.check_sampling(dict(P.TINY, vocab_size=97), 20, 10, temperature=1.1)
+    assert r['boundary'] <= 2
+
+
 def test_train_parity_cfg1(gpu):
     P.check_train(P.CFG1, B=64, T=100, tol=TOL)
 

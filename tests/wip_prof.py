@@ -1,0 +1,40 @@
+"""In-kernel phase counters of the BPTT kernel (PMG_DEBUG=0x8000); not collected by pytest."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from paccmann_generator_amd import _ffi, ops
+from paccmann_generator_amd.reinforce import pad_rows_on_device
+cfg = dict(bench.CONFIGS[os.environ.get('CFG', 'cfg2')])
+B, T = int(os.environ.get('B', cfg['batch'])), cfg['length']
+dev = torch.device('cuda')
+learner = bench.build_learner(cfg, dev)
+dec = learner.generator.decoder
+w = dec.weights()
+torch.manual_seed(1)
+latent = torch.randn(1, B, cfg['latent_dim'], device=dev)
+rewards = torch.rand(B, device=dev)
+tokens, lens = ops.decode(w, latent, 2, 3, T, temperature=0.8, seed=1, early_exit=False)
+padded = pad_rows_on_device(tokens, lens, 3, t_max=T + 2)
+Tt = padded.shape[0]
+with torch.no_grad():
+    h0 = dec.latent_to_hidden(latent.repeat(dec.n_layers, 1, 1)).contiguous()
+shape = w.shape(B, Tt)
+ws = torch.empty(_ffi.workspace_bytes(shape, _ffi.PMG_MODE_TRAIN), dtype=torch.uint8, device=dev)
+wstruct, keep = w.struct(False)
+logp = torch.empty(Tt - 1, B, device=dev)
+grads = [torch.empty_like(p) for p in w.flat()]
+gstruct, keep2 = _ffi.pack_weight_struct(_ffi.PmgGrads, ops.DecoderWeights.unflatten(grads, dec.n_layers), dec.n_layers)
+gh0 = torch.empty_like(h0)
+loss = torch.empty(1, device=dev)
+st = _ffi.current_stream()
+def fwd():
+    _ffi.check(_ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(h0), _ffi._ptr(logp), None, _ffi._ptr(ws), st), 'fwd')
+def bwd(flags):
+    _ffi.check(_ffi.lib.pmg_reinforce_bwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(rewards), 1.0 / B, flags, C.byref(gstruct), _ffi._ptr(gh0), _ffi._ptr(loss), _ffi._ptr(ws), st), 'bwd')
+fwd(); bwd(_ffi.PMG_FLAG_SKIP_WGRAD); torch.cuda.synchronize()
+os.environ['PMG_DEBUG'] = '0x8000'
+for which in os.environ.get('WHICH', 'fwd,bwd').split(','):
+    if which == 'fwd': fwd()
+    else: bwd(_ffi.PMG_FLAG_SKIP_WGRAD)
+    torch.cuda.synchronize()
