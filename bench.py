@@ -200,6 +200,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-phases', action='store_true')
     args = ap.parse_args()
+    if os.environ.get('PMG_HANG_DUMP'):  # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['PMG_HANG_DUMP']), exit=True)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -211,8 +214,12 @@ def main():
     pg = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # RCCL ("nccl" on ROCm) over xGMI.  PMG_DIST_BACKEND=gloo rehearses the N>1 code path on a
+        # box with fewer GPUs than ranks (ranks then share devices; timing is meaningless there).
+        backend = os.environ.get('PMG_DIST_BACKEND', 'nccl')
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl')
+        dist.init_process_group(backend)
         pg = dist.group.WORLD
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
@@ -221,6 +228,7 @@ def main():
     B = args.batch or cfg['batch']
     T = cfg['length']
     learner = build_learner(cfg, device, pg)
+    from paccmann_generator_amd import dp
     from paccmann_generator_amd.reinforce import pad_rows_on_device
 
     # synthetic, resident inputs
@@ -251,7 +259,7 @@ def main():
     el = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([el], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dp.all_reduce_(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
     ms_per_step = 1e3 * el / args.steps
@@ -285,6 +293,13 @@ def main():
             result['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(result), flush=True)
     if world > 1:
+        # replicas must still be identical after the steps (no broadcast is ever done)
+        flat = torch.cat([p.detach().reshape(-1) for p in learner.generator.decoder.parameters()])
+        lo, hi = flat.clone(), flat.clone()
+        dp.all_reduce_(lo, op=dist.ReduceOp.MIN)
+        dp.all_reduce_(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise SystemExit(f'rank {rank}: decoder replicas diverged')
         dist.barrier()
         dist.destroy_process_group()
 

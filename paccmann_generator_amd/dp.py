@@ -19,6 +19,24 @@ import torch
 import torch.distributed as dist
 
 
+def _stage_on_host(t: torch.Tensor, group=None) -> bool:
+    """gloo moves device tensors through the host itself, and that path hangs on this ROCm stack:
+    stage explicitly.  RCCL ("nccl") reduces device memory in place."""
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+def all_reduce_(t: torch.Tensor, op=None, group=None) -> torch.Tensor:
+    """In-place all-reduce that works for device tensors under both RCCL and gloo."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if _stage_on_host(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous [lo, hi) slice of ``n`` sequences owned by ``rank`` (sizes differ by <= 1)."""
     base, rem = divmod(int(n), int(world))
@@ -31,7 +49,7 @@ def global_sum(value: float, device, group=None) -> float:
     if group is None and not (dist.is_available() and dist.is_initialized()):
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    all_reduce_(t, group=group)
     return float(t.item())
 
 
@@ -46,7 +64,7 @@ def all_reduce_gradients_(params: Iterable[torch.nn.Parameter], group=None) -> i
     if not ps:
         return 0
     flat = torch.cat([p.grad.reshape(-1) for p in ps])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    all_reduce_(flat, group=group)
     off = 0
     for p in ps:
         n = p.numel()

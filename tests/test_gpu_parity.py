@@ -181,3 +181,57 @@ def test_shape_errors_are_reported(gpu):
         _ffi.workspace_bytes(s, _ffi.PMG_MODE_TRAIN)
     with pytest.raises(_ffi.PmgError):
         _ffi._ptr(torch.zeros(3))  # CPU tensor: no CPU path
+
+
+def test_full_size_chunk_additivity_and_determinism(gpu):
+    """BASELINE.json configs[1] at full size (hidden 512, stack 50x50, B=4096, T=130): properties
+    that do not need the oracle.  (i) decode is deterministic and sharding-invariant; (ii) the
+    gradient of the whole batch equals the sum of the gradients of its two halves (each with
+    scale 1/B) -- the data-parallel identity; (iii) log-probs of a half equal the rows of the whole;
+    (iv) sum of per-token log-probs reproduces the loss."""
+    from paccmann_generator_amd import ops
+    from paccmann_generator_amd.reinforce import pad_rows_on_device
+    _, pdec = P.make_pair(P.CFG2)
+    B, T = 4096, 128
+    torch.manual_seed(1)
+    latent = torch.randn(B, P.CFG2['latent_dim'], device='cuda')
+    w = pdec.weights()
+    tok, lens = ops.decode(w, latent, P.START, P.STOP, T, 0.8, seed=1234, early_exit=False)
+    tok2, lens2 = ops.decode(w, latent, P.START, P.STOP, T, 0.8, seed=1234, early_exit=True)
+    a, al = ops.decode(w, latent[:1000], P.START, P.STOP, T, 0.8, seed=1234, early_exit=False)
+    b, bl = ops.decode(w, latent[1000:], P.START, P.STOP, T, 0.8, seed=1234, seq_index_base=1000, early_exit=False)
+    assert torch.equal(tok, torch.cat([a, b])) and torch.equal(lens, torch.cat([al, bl]))
+    assert torch.equal(lens, lens2)
+    assert int(tok.min()) >= 0 and int(tok.max()) < P.CFG2['vocab_size']
+    padded = pad_rows_on_device(tok, lens, P.STOP, t_max=T + 2)
+    # rows are tokens[:len] + [stop, stop] + zeros (reinforce.py:177-184, reinforce_omics.py:304)
+    r = 17
+    n = int(lens[r])
+    assert padded[:n, r].tolist() == tok[r, :n].tolist() and padded[n:n + 2, r].tolist() == [P.STOP] * 2
+    assert int(padded[n + 2:, r].abs().sum()) == 0
+    with torch.no_grad():
+        h0 = pdec.latent_to_hidden(latent.unsqueeze(0)).contiguous()
+    torch.manual_seed(2)
+    R = torch.rand(B, device='cuda')
+
+    def run(sl):
+        for p in pdec.parameters():
+            p.grad = None
+        loss, logp = ops.reinforce_loss(w, padded[:, sl].contiguous(), h0[:, sl].contiguous(), R[sl].contiguous(),
+                                        1.0 / B)
+        loss.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in pdec.parameters() if p.grad is not None])
+        return loss.item(), logp, g
+
+    lw, lpw, gw = run(slice(0, B))
+    l1, lp1, g1 = run(slice(0, 2048))
+    l2, lp2, g2 = run(slice(2048, B))
+    assert torch.isfinite(gw).all() and torch.isfinite(lpw).all()
+    assert abs(lw - (l1 + l2)) < 1e-5 * abs(lw)
+    assert float((gw - (g1 + g2)).abs().max() / gw.abs().max()) < 1e-5
+    assert torch.equal(lpw[:, :2048], lp1) and torch.equal(lpw[:, 2048:], lp2)
+    ref_loss = -float((lpw.double() * R.double().unsqueeze(0)).sum()) / B
+    assert abs(lw - ref_loss) < 1e-5 * abs(ref_loss)
+    # run-to-run determinism of the gradients (no atomics anywhere)
+    lw2, _, gw2 = run(slice(0, B))
+    assert lw2 == lw and torch.equal(gw, gw2)
