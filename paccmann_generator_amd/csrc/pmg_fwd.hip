@@ -31,10 +31,57 @@ __device__ __forceinline__ void st4(float* p, const f32x4 v) {
 // Two register sets (wa, wb), loop unrolled by two: the loads of group kg+1 are in flight
 // while the MFMAs of group kg run (the sched_barriers keep hipcc from re-fusing load and
 // use, which it otherwise does).  KG is even.
+// Side work interleaved with a GEMM K loop.  A side job is called once per double K group with a
+// STATIC slot number (the loop is unrolled by four), so the value a call loads lands in the
+// register it is consumed from four calls later: no register copies of in-flight data, hence no
+// early waits.  vmcnt counts loads AND stores in issue order, so a wait for weights that were
+// requested after the side job's store also waits for that store's acknowledgement: the side job
+// sits right after the loads of the second half group, which gives its store two half groups of
+// MFMAs before the next wait that covers it.
 struct NoSide {
-  __device__ __forceinline__ void operator()() const {}
+  static constexpr bool kActive = false;
+  template <int U> __device__ __forceinline__ void step() const {}
 };
 
+// Stack update of one thread: column (w, 4 sequences), rows d0 .. d0+rows-1, one row per call.
+//   new[d] = no_op*old[d] + push*old[d-1] + pop*old[d+1]
+// q[] is a ring of old rows requested ahead (slot of old[d0+1+k] is (k-1)&3); loads are
+// unconditional at a clamped row and masked when consumed (rows beyond old_hi read as zero).
+struct StackSide {
+  static constexpr bool kActive = true;
+  const float* Sold; float* Snew;
+  f32x4 anoop, apush, apop, s_prev, s_cur, q[4];
+  int d0, rows, old_hi, Dm1, sj, dch;  // dch: calls after which every thread of the workgroup is done
+  unsigned rstr;  // floats per stack row slab line: W*16
+  bool on, nt;
+  template <int U> __device__ __forceinline__ void step() {
+    if (sj >= dch) return;  // uniform: nothing left for anybody
+    const int d = d0 + sj;
+    f32x4 nxt = q[U];
+    if (sj + 4 < dch) {  // uniform: somebody will consume this slot again
+      const int dn = d + 5;
+      const int dc = dn < Dm1 ? dn : Dm1;
+      q[U] = *reinterpret_cast<const f32x4*>(Sold + (size_t)dc * rstr);
+    }
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    nxt = (d + 1 <= old_hi) ? nxt : z4;
+    const f32x4 nw = anoop * s_cur + apush * s_prev + apop * nxt;
+    if (on && sj < rows) {
+      if (nt) pmg_st4h<2>(Snew + (size_t)d * rstr, nw);
+      else *reinterpret_cast<f32x4*>(Snew + (size_t)d * rstr) = nw;
+    }
+    s_prev = s_cur;
+    s_cur = nxt;
+    ++sj;
+  }
+};
+
+// acc{r,z,t}[u0..u0+TPP) += W[tiles 3*u0 ..] * X   over KG groups of 16 columns.
+// Weights come through the buffer resource `rs`: voff = lane*16, soff = byte offset of
+// (first tile, group 0); xrow = this lane's LDS row + 4*(lane>>4).
+// Two register sets (wa, wb): the loads of group kg+1 are in flight while the MFMAs of group kg
+// run (the sched_barriers keep hipcc from re-fusing load and use, which it otherwise does).
+// KG is even; with an active side job KG is a multiple of 8 and the loop is unrolled by four.
 template <int UPW, int TPP, class Side>
 __device__ __forceinline__ void gemm3_pass(f32x4 (&ar)[UPW], f32x4 (&az)[UPW], f32x4 (&at)[UPW], const int u0,
                                            const __amdgpu_buffer_rsrc_t rs, const unsigned voff,
@@ -50,29 +97,40 @@ __device__ __forceinline__ void gemm3_pass(f32x4 (&ar)[UPW], f32x4 (&az)[UPW], f
     az[u0 + uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[3 * uu + 1].C, x.C, az[u0 + uu], 0, 0, 0); \
     at[u0 + uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[3 * uu + 2].C, x.C, at[u0 + uu], 0, 0, 0); \
   }
-  PMG_LOAD(wa, 0)
-#pragma unroll 1
-  for (int kg = 0; kg < KG; kg += 2) {
-    PMG_LOAD(wb, kg + 1)
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      const float4 x = *reinterpret_cast<const float4*>(xrow + 16 * kg);
-      PMG_STEP(wa, x) PMG_STEP(wa, y) PMG_STEP(wa, z) PMG_STEP(wa, w)
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      const int kn = (kg + 2 < KG) ? kg + 2 : kg;
-      PMG_LOAD(wa, kn)
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      const float4 x = *reinterpret_cast<const float4*>(xrow + 16 * kg + 16);
-      PMG_STEP(wb, x) PMG_STEP(wb, y) PMG_STEP(wb, z) PMG_STEP(wb, w)
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    side();  // one unit of side work (stack row) per double group, hidden under the MFMAs
-    __builtin_amdgcn_sched_barrier(0);
+#define PMG_DGROUP(U, kgq)                                                                       \
+  {                                                                                              \
+    const int kg_ = (kgq);                                                                       \
+    PMG_LOAD(wb, kg_ + 1)                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    side.template step<U>();                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    {                                                                                            \
+      const float4 x = *reinterpret_cast<const float4*>(xrow + 16 * kg_);                        \
+      PMG_STEP(wa, x) PMG_STEP(wa, y) PMG_STEP(wa, z) PMG_STEP(wa, w)                            \
+    }                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    {                                                                                            \
+      const int kn = (kg_ + 2 < KG) ? kg_ + 2 : kg_;                                             \
+      PMG_LOAD(wa, kn)                                                                           \
+    }                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    {                                                                                            \
+      const float4 x = *reinterpret_cast<const float4*>(xrow + 16 * kg_ + 16);                   \
+      PMG_STEP(wb, x) PMG_STEP(wb, y) PMG_STEP(wb, z) PMG_STEP(wb, w)                            \
+    }                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
   }
+  PMG_LOAD(wa, 0)
+  if constexpr (Side::kActive) {
+#pragma unroll 1
+    for (int kg = 0; kg < KG; kg += 8) {
+      PMG_DGROUP(0, kg) PMG_DGROUP(1, kg + 2) PMG_DGROUP(2, kg + 4) PMG_DGROUP(3, kg + 6)
+    }
+  } else {
+#pragma unroll 1
+    for (int kg = 0; kg < KG; kg += 2) PMG_DGROUP(0, kg)
+  }
+#undef PMG_DGROUP
 #undef PMG_STEP
 #undef PMG_LOAD
 }
@@ -272,18 +330,28 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     const int st_d1 = (st_d0 + st_dch < st_nrows) ? st_d0 + st_dch : st_nrows;
     const int st_rows = st_d1 - st_d0;
     const bool st_on = st_col && st_d0 < st_d1 && !(dbg & 0x100) && i < N;
-    f32x4 s_prev = zero4, s_cur = zero4, r0 = zero4, r1 = zero4, r2 = zero4;
-    if (st_on) {
-      if (st_d0 > 0 && st_d0 - 1 <= st_old_hi) s_prev = ld4(st_Sold + (size_t)(st_d0 - 1) * W * 16);
-      if (st_d0 <= st_old_hi) s_cur = ld4(st_Sold + (size_t)st_d0 * W * 16);
-      if (st_d0 + 1 <= st_old_hi) r0 = ld4(st_Sold + (size_t)(st_d0 + 1) * W * 16);
-      if (st_d0 + 2 <= st_old_hi) r1 = ld4(st_Sold + (size_t)(st_d0 + 2) * W * 16);
-      if (st_d0 + 3 <= st_old_hi) r2 = ld4(st_Sold + (size_t)(st_d0 + 3) * W * 16);
-    }
-
     // target token of step i-1 (teacher): requested here, used after the extras GEMM
     int cs_y = 0;
     if (teacher && i >= 1 && row0 + cs_bb < B) cs_y = (int)a.tok_in[(size_t)i * B + row0 + cs_bb];
+
+    // old rows d0-1, d0, d0+1 (first row of this thread) and the ring d0+2 .. d0+5: requested here,
+    // unconditionally at clamped rows (inactive threads read row 0 of their column), masked when used
+    StackSide stk;
+    stk.Sold = st_Sold; stk.rstr = (unsigned)W * 16u; stk.Dm1 = D - 1;
+    stk.d0 = st_on ? st_d0 : 0; stk.dch = st_dch; stk.rows = st_rows; stk.old_hi = st_old_hi; stk.on = st_on; stk.nt = keep;
+    f32x4 st_pm, st_c0, st_n0;
+    {
+      const int dA = stk.d0 > 0 ? stk.d0 - 1 : 0;
+      const int dB = stk.d0 + 1 < D ? stk.d0 + 1 : D - 1;
+      st_pm = ld4(st_Sold + (size_t)dA * stk.rstr);
+      st_c0 = ld4(st_Sold + (size_t)stk.d0 * stk.rstr);
+      st_n0 = ld4(st_Sold + (size_t)dB * stk.rstr);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int dq = stk.d0 + 2 + j;
+        stk.q[j] = ld4(st_Sold + (size_t)(dq < D ? dq : D - 1) * stk.rstr);
+      }
+    }
 
     // ------------------------------------------------------------ extras GEMM
     if (!(dbg & 0x200)) {
@@ -394,10 +462,9 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     // new[d] = no_op*old[d] + push*old[d-1] + pop*old[d+1]   (old[-1] = push value, old[D] = 0).
     // Each thread walks its depth range one row per side-job call; rows d0-1 .. d0+3 were
     // requested before the extras GEMM, every call requests row d+4.
-    f32x4 apush = zero4, apop = zero4, anoop = zero4;
+    f32x4 apush = zero4, apop = zero4, anoop = zero4, pv = zero4;
     float* const st_Snew = a.SB + ((size_t)st_slot_new * G + g) * a.SW + st_cofs;
     if (st_on) {
-      f32x4 pv;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float* cx = xex + (4 * st_bq + j) * XP;
@@ -408,42 +475,36 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
         apush[j] = e0 * inv; apop[j] = e1 * inv; anoop[j] = e2 * inv;
         pv[j] = fast_tanh(cx[3 + st_w]);
       }
-      if (st_d0 == 0) {
-        s_prev = pv;
-        if (keep) {
-          if (st_w == 0) {
-            float* ct = a.CT + ((size_t)i * G + g) * 64;
-            st4(ct + 0 * 16 + 4 * st_bq, apush);
-            st4(ct + 1 * 16 + 4 * st_bq, apop);
-            st4(ct + 2 * 16 + 4 * st_bq, anoop);
-          }
-          st4(a.PV + ((size_t)i * G + g) * 1024 + st_w * 16 + 4 * st_bq, pv);
+      if (st_d0 == 0 && keep) {
+        if (st_w == 0) {
+          float* ct = a.CT + ((size_t)i * G + g) * 64;
+          st4(ct + 0 * 16 + 4 * st_bq, apush);
+          st4(ct + 1 * 16 + 4 * st_bq, apop);
+          st4(ct + 2 * 16 + 4 * st_bq, anoop);
         }
+        st4(a.PV + ((size_t)i * G + g) * 1024 + st_w * 16 + 4 * st_bq, pv);
       }
     }
-    int sj = 0;  // side-job calls so far (uniform)
-    auto stack_row = [&]() {
-      const int d = st_d0 + sj;
-      const bool act = st_on && sj < st_rows;
-      const int dn = d + 4;
-      f32x4 ldv = zero4;
-      if (act && dn <= st_old_hi && dn <= st_d1) ldv = ld4(st_Sold + (size_t)dn * W * 16);
-      const f32x4 nxt = r0;
-      r0 = r1; r1 = r2; r2 = ldv;
-      if (act) {
-        const f32x4 nw = anoop * s_cur + apush * s_prev + apop * nxt;
-        if (keep) pmg_st4h<2>(st_Snew + (size_t)d * W * 16, nw);
-        else st4(st_Snew + (size_t)d * W * 16, nw);
-        if (d == 0) {
+    // first row of every thread now (row 0 is the stack top the W_ih product needs right after
+    // the W_hh product); the remaining rows stream under the W_hh GEMM, one per double K group
+    stk.Snew = st_Snew; stk.anoop = anoop; stk.apush = apush; stk.apop = apop; stk.sj = 1;
+    {
+      const f32x4 pm = (st_d0 == 0) ? pv : ((st_d0 - 1 <= st_old_hi) ? st_pm : zero4);
+      const f32x4 c0 = (st_d0 <= st_old_hi) ? st_c0 : zero4;
+      const f32x4 n0 = (st_d0 + 1 <= st_old_hi) ? st_n0 : zero4;
+      if (st_on) {
+        const f32x4 nw = anoop * c0 + apush * pm + apop * n0;
+        if (keep) pmg_st4h<2>(st_Snew + (size_t)st_d0 * stk.rstr, nw);
+        else st4(st_Snew + (size_t)st_d0 * stk.rstr, nw);
+        if (st_d0 == 0) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) xtop[(4 * st_bq + j) * PMG_XTP + st_w] = nw[j];
           if (keep) st4(a.TP + ((size_t)i * G + g) * 1024 + st_w * 16 + 4 * st_bq, nw);
         }
       }
-      s_prev = s_cur;
-      s_cur = nxt;
-      ++sj;
-    };
+      stk.s_prev = c0;
+      stk.s_cur = n0;
+    }
 
     // ------------------------------------------------------------ layer 0: gh GEMM
 #pragma unroll
@@ -454,8 +515,10 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
       ai[u] = ld4(a.BG[0] + 2 * H + j0);
       ah[u] = ld4(a.BG[0] + 3 * H + j0);
     }
-    if (!(dbg & 0x400)) gemm3<UPW, TPP>(ar, az, ah, wrs, voff, a.oWHH[0], KGH, h_lds + (size_t)b * HP + 4 * q, wave, stack_row);
-    while (sj < st_dch) stack_row();  // rows the GEMM loop did not reach
+    if (!(dbg & 0x400)) gemm3<UPW, TPP>(ar, az, ah, wrs, voff, a.oWHH[0], KGH, h_lds + (size_t)b * HP + 4 * q, wave, stk);
+    while (stk.sj < st_dch) {  // rows the GEMM loop did not reach (four calls keep the ring slots aligned)
+      stk.template step<0>(); stk.template step<1>(); stk.template step<2>(); stk.template step<3>();
+    }
     PMG_TICK(3)
     __syncthreads();  // B2: stack top + token visible; every read of h_lds[0] (old) is done
 
