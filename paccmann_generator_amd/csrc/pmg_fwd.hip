@@ -339,18 +339,16 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     StackSide stk;
     stk.Sold = st_Sold; stk.rstr = (unsigned)W * 16u; stk.Dm1 = D - 1;
     stk.d0 = st_on ? st_d0 : 0; stk.dch = st_dch; stk.rows = st_rows; stk.old_hi = st_old_hi; stk.on = st_on; stk.nt = keep;
-    f32x4 st_pm, st_c0, st_n0;
-    {
-      const int dA = stk.d0 > 0 ? stk.d0 - 1 : 0;
-      const int dB = stk.d0 + 1 < D ? stk.d0 + 1 : D - 1;
-      st_pm = ld4(st_Sold + (size_t)dA * stk.rstr);
-      st_c0 = ld4(st_Sold + (size_t)stk.d0 * stk.rstr);
-      st_n0 = ld4(st_Sold + (size_t)dB * stk.rstr);
+    f32x4 st_pm = zero4, st_c0 = zero4, st_n0 = zero4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int dq = stk.d0 + 2 + j;
-        stk.q[j] = ld4(st_Sold + (size_t)(dq < D ? dq : D - 1) * stk.rstr);
-      }
+    for (int j = 0; j < 4; ++j) stk.q[j] = zero4;
+    if (st_on) {  // only rows that hold data are requested (memory operations are not free here)
+      if (st_d0 > 0 && st_d0 - 1 <= st_old_hi) st_pm = ld4(st_Sold + (size_t)(st_d0 - 1) * stk.rstr);
+      if (st_d0 <= st_old_hi) st_c0 = ld4(st_Sold + (size_t)st_d0 * stk.rstr);
+      if (st_d0 + 1 <= st_old_hi) st_n0 = ld4(st_Sold + (size_t)(st_d0 + 1) * stk.rstr);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (st_d0 + 2 + j <= st_old_hi && j + 1 < st_dch) stk.q[j] = ld4(st_Sold + (size_t)(st_d0 + 2 + j) * stk.rstr);
     }
 
     // ------------------------------------------------------------ extras GEMM
