@@ -41,6 +41,8 @@ CONFIGS = {
     'cfg4': dict(embedding_size=128, rnn_cell_size=1024, vocab_size=60, stack_width=50, stack_depth=50,
                  n_layers=2, latent_dim=256, pad_index=0, batch=4096, length=256),
 }
+KIND = {'cfg1': 'omics-conditioned (reinforce_omics path)', 'cfg2': 'omics-conditioned',
+        'cfg4': 'protein-conditioned (reinforce_proteins path)'}
 START, STOP = 2, 3
 
 
@@ -271,7 +273,7 @@ def main():
         'value': tokens_per_s, 'unit': 'tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'{args.config}: omics-conditioned decode+REINFORCE, hidden {cfg["rnn_cell_size"]}, '
+        'config': {'workload': f'{args.config}: {KIND[args.config]} decode+REINFORCE, hidden {cfg["rnn_cell_size"]}, '
                                f'stack {cfg["stack_depth"]}x{cfg["stack_width"]}, layers {cfg["n_layers"]}, '
                                f'vocab {cfg["vocab_size"]}, emb {cfg["embedding_size"]}, latent {cfg["latent_dim"]}',
                    'batch_per_gpu': B, 'global_batch': B * world, 'len': T, 'parallelism': f'dp{world}',

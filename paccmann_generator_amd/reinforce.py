@@ -39,11 +39,12 @@ def _rdkit_validity():
 class Reinforce(object):
 
     def __init__(self, generator, encoder, params, model_name, logger, is_valid: Optional[Callable] = None,
-                 reward_fn: Optional[Callable] = None, process_group=None):
+                 reward_fn: Optional[Callable] = None, process_group=None, score_fn: Optional[Callable] = None):
         """Same positional arguments as reinforce.py:16.  Keyword-only extras:
 
         is_valid:      host validity check replacing Chem.MolFromSmiles (reinforce.py:195)
         reward_fn:     host reward ``f(smiles, target) -> array`` (reinforce_omics.py:209-222)
+        score_fn:      host scoring used by generate_compounds_and_evaluate (defaults to reward_fn)
         process_group: torch.distributed group for data-parallel latent sharding
         """
         super(Reinforce, self).__init__()
@@ -69,6 +70,7 @@ class Reinforce(object):
         self.weights_path = os.path.join(self.model_path, 'weights/{}')
         self.is_valid = is_valid if is_valid is not None else _rdkit_validity()
         self.reward_fn = reward_fn
+        self.score_fn = score_fn
         self.process_group = process_group
 
         # reinforce.py:59-77
@@ -203,6 +205,19 @@ class Reinforce(object):
             raise RuntimeError('no reward function: pass reward_fn= (drug evaluators are out of scope)')
         return self.reward_fn(valid_smiles, target)
 
+    def _evaluate(self, latent_z, target, return_latent, remove_invalid):
+        """Sampling-only entry shared by generate_compounds_and_evaluate of the subclasses
+        (reinforce_omics.py:164-180, reinforce_proteins.py:180-198): decode, then score the valid
+        molecules with the host-side ``score_fn`` (the predictor forward is out of scope)."""
+        valid_smiles, valid_nums, _ = self.get_smiles_from_latent(latent_z, remove_invalid=remove_invalid)
+        score_fn = getattr(self, 'score_fn', None) or self.reward_fn
+        if score_fn is None:
+            raise RuntimeError('no scoring function: pass score_fn= or reward_fn=')
+        preds = np.asarray(score_fn(valid_smiles, target)) if len(valid_smiles) else np.zeros(0)
+        if return_latent:
+            return valid_smiles, preds, latent_z
+        return valid_smiles, preds
+
     # ------------------------------------------------------------------ checkpoints (reinforce.py:261-285)
     def load(self, generator_filepath=None, encoder_filepath=None, *args, **kwargs):
         if generator_filepath is not None:
@@ -244,6 +259,19 @@ class ReinforceOmic(Reinforce):
         latent_z = self.encode_cell_line(cell_line, batch_size)
         return self._policy_gradient(latent_z, cell_line)
 
+    def generate_compounds_and_evaluate(self, epoch, batch_size, cell_line=None, primed_drug=' ',
+                                        return_latent=False, remove_invalid=True):
+        """reinforce_omics.py:97-180: random latents when cell_line is None (:122-126), else the
+        encoder mean repeated batch_size times (:128-145); decode; score."""
+        if type(primed_drug) != str:
+            raise TypeError('Provide drug as SMILES string.')
+        if cell_line is None:
+            latent_z = torch.randn(1, batch_size, self.generator.decoder.latent_dim, device=self.device)
+        else:
+            with torch.no_grad():
+                latent_z = self.encode_cell_line(cell_line, batch_size)
+        return self._evaluate(latent_z, cell_line, return_latent, remove_invalid)
+
 
 class ReinforceProtein(Reinforce):
     """reinforce_proteins.py.  ``protein_df``: frame indexed by protein name whose row holds
@@ -270,6 +298,52 @@ class ReinforceProtein(Reinforce):
         """reinforce_proteins.py:267-331."""
         latent_z = self.encode_protein(protein, batch_size)
         return self._policy_gradient(latent_z, protein)
+
+    def generate_compounds_and_evaluate(self, epoch, batch_size, protein=None, primed_drug=' ',
+                                        return_latent=False, remove_invalid=True):
+        """reinforce_proteins.py:133-198."""
+        if type(primed_drug) != str:
+            raise TypeError('Provide drug as SMILES string.')
+        with torch.no_grad():
+            latent_z = self.encode_protein(protein, batch_size)
+        return self._evaluate(latent_z, protein, return_latent, remove_invalid)
+
+
+class ReinforceMultiModalSets(Reinforce):
+    """Hot path of reinforce_sets.py: the same sampling + teacher-forced REINFORCE loop
+    (reinforce_sets.py:438-502) conditioned on a set of embeddings.  What differs from the omics
+    / protein classes is in-tree and reproduced: the latent is the mean of the tensors the set
+    encoder returns (:464), the reward takes both targets, and there is NO gradient clipping
+    (:499-501).  Building the input set (reinforce_sets.py get_set: predictor embeddings of the
+    cell line and the protein) is host work outside the path: pass ``set_fn(cell_line, protein,
+    batch_size) -> input_set``."""
+
+    def __init__(self, generator, encoder, params, model_name, logger, set_fn=None, **kw):
+        self.set_fn = set_fn
+        super(ReinforceMultiModalSets, self).__init__(generator, encoder, params, model_name, logger, **kw)
+        self.grad_clipping = None
+
+    def update_params(self, params):
+        super(ReinforceMultiModalSets, self).update_params(params)
+        self.grad_clipping = None
+
+    def encode_set(self, cell_line, protein, batch_size):
+        if self.set_fn is None:
+            raise RuntimeError('no set builder: pass set_fn=')
+        input_set = self.set_fn(cell_line, protein, batch_size)
+        encoder_output = self.encoder(input_set.to(self.device) if torch.is_tensor(input_set) else input_set)
+        return torch.mean(torch.stack(list(encoder_output)), dim=0)
+
+    def get_reward(self, valid_smiles, target):
+        protein, cell_line = target
+        if self.reward_fn is None:
+            raise RuntimeError('no reward function: pass reward_fn=')
+        return self.reward_fn(valid_smiles, protein, cell_line)
+
+    def policy_gradient(self, cell_line, protein, epoch, batch_size=10):
+        """reinforce_sets.py:438-502."""
+        latent_z = self.encode_set(cell_line, protein, batch_size)
+        return self._policy_gradient(latent_z, (protein, cell_line))
 
 
 def pad_rows_on_device(tokens: torch.Tensor, lens: torch.Tensor, stop_index: int, t_max: Optional[int] = None):
