@@ -86,7 +86,9 @@ __device__ __forceinline__ void gemm_lin(f32x4 (&acc)[NT], const __amdgpu_buffer
   }
 }
 
-template <int UPW>
+// MULTI: more than one GRU layer (only then is the W_ih^T product of a layer carried to the layer
+// below; a single-layer kernel does not hold those accumulators).
+template <int UPW, bool MULTI>
 __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int H = a.H, XP = a.XP, W = a.W, D = a.D, V = a.V, L = a.L, B = a.B, G = a.G, N = a.N;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
 #pragma unroll
         for (int u = 0; u < UPW; ++u) {
           dh[u] = ld4(dhc + ((size_t)(l * UT + wave * UPW + u)) * 256 + lane * 4);
-          if (l < L - 1) dh[u] += dxa[u];
+          if (MULTI && l < L - 1) dh[u] += dxa[u];
           acc_hh[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
           acc_dx[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
             const unsigned so = a.oWHHt[l] + ((unsigned)(wave * UPW) * KG3 + (unsigned)c * 24u) * 1024u;
             if (!(dbg & 0x400)) gemm_chunk<UPW>(acc_hh, wrs, voff, so, KG3 * 1024u, xb, 0, 1, 3);
           }
-          if (l > 0) {
+          if (MULTI && l > 0) {
             const unsigned so = a.oWIHt[l] + ((unsigned)(wave * UPW) * KG3 + (unsigned)c * 24u) * 1024u;
             gemm_chunk<UPW>(acc_dx, wrs, voff, so, KG3 * 1024u, xb, 0, 1, 2);
           } else if (wave < PMG_KS / 16) {
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
 #pragma unroll
         for (int u = 0; u < UPW; ++u) {
           st4(dhc + ((size_t)(l * UT + wave * UPW + u)) * 256 + lane * 4, acc_hh[u]);
-          dxa[u] = acc_dx[u];
+          if (MULTI) dxa[u] = acc_dx[u];
         }
         if (l == 0 && wave < PMG_KS / 16) st4(dtl + b * PMG_XTP + 16 * wave + 4 * q, acc_top[0]);
       }
@@ -396,10 +398,10 @@ size_t pmg_bwd_lds_bytes(const BwdArgs* a) {
   return ((size_t)2 * 16 * PMG_CP + (size_t)16 * a->XP + 16 * PMG_XTP + PMG_WAVES * 48 + 16) * sizeof(float);
 }
 
-template <int UPW>
+template <int UPW, bool MULTI>
 static hipError_t launch_bwd_t(const BwdArgs* a, hipStream_t st) {
   const size_t lds = pmg_bwd_lds_bytes(a);
-  auto kern = pmg_bwd_kernel<UPW>;
+  auto kern = pmg_bwd_kernel<UPW, MULTI>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return e;
@@ -408,11 +410,12 @@ static hipError_t launch_bwd_t(const BwdArgs* a, hipStream_t st) {
 }
 
 hipError_t pmg_launch_bwd(const BwdArgs* a, hipStream_t st) {
+  const bool m = a->L > 1;
   switch (a->H) {
-    case 128: return launch_bwd_t<1>(a, st);
-    case 256: return launch_bwd_t<2>(a, st);
-    case 512: return launch_bwd_t<4>(a, st);
-    case 1024: return launch_bwd_t<8>(a, st);
+    case 128: return m ? launch_bwd_t<1, true>(a, st) : launch_bwd_t<1, false>(a, st);
+    case 256: return m ? launch_bwd_t<2, true>(a, st) : launch_bwd_t<2, false>(a, st);
+    case 512: return m ? launch_bwd_t<4, true>(a, st) : launch_bwd_t<4, false>(a, st);
+    case 1024: return m ? launch_bwd_t<8, true>(a, st) : launch_bwd_t<8, false>(a, st);
   }
   return hipErrorInvalidValue;
 }
