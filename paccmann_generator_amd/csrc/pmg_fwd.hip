@@ -200,7 +200,9 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return copysignf(t, x);
 }
 
-template <int UPW, int TPP>
+// MODE (decode / teacher / step) and MULTI (more than one layer) are compile-time: each variant
+// carries only the registers and branches it needs.
+template <int UPW, int TPP, int MODE, bool MULTI>
 __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int H = a.H, HP = a.HP, XP = a.XP, W = a.W, D = a.D, V = a.V, L = a.L, B = a.B, G = a.G, N = a.N;
@@ -219,9 +221,9 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
   const int row0 = g * PMG_ROWS;
   const __amdgpu_buffer_rsrc_t wrs = pmg_rsrc(a.wbase, a.wbytes);
   const unsigned voff = (unsigned)lane * 16u;
-  const bool teacher = (a.mode == PMG_FWD_TEACHER);
-  const bool decode = (a.mode == PMG_FWD_DECODE);
-  const bool stepm = (a.mode == PMG_FWD_STEP);
+  constexpr bool teacher = (MODE == PMG_FWD_TEACHER);
+  constexpr bool decode = (MODE == PMG_FWD_DECODE);
+  constexpr bool stepm = (MODE == PMG_FWD_STEP);
   const bool keep = teacher && !(a.dbg & 0x1000);  // keep per-step history for the backward
   const int dbg = a.dbg;
 
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     PMG_TICK(6)
 
     // ------------------------------------------------------------ layers 1..L-1
-    for (int l = 1; l < L; ++l) {
+    for (int l = 1; MULTI && l < L; ++l) {
 #pragma unroll
       for (int u = 0; u < UPW; ++u) {
         const int j0 = 16 * (wave * UPW + u) + 4 * q;
@@ -640,10 +642,10 @@ size_t pmg_fwd_lds_bytes(const FwdArgs* a) {
   return fl * sizeof(float);
 }
 
-template <int UPW, int TPP>
+template <int UPW, int TPP, int MODE, bool MULTI>
 static hipError_t launch_fwd_t(const FwdArgs* a, hipStream_t st) {
   const size_t lds = pmg_fwd_lds_bytes(a);
-  auto kern = pmg_fwd_kernel<UPW, TPP>;
+  auto kern = pmg_fwd_kernel<UPW, TPP, MODE, MULTI>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return e;
@@ -651,12 +653,26 @@ static hipError_t launch_fwd_t(const FwdArgs* a, hipStream_t st) {
   return hipGetLastError();
 }
 
+template <int UPW, int TPP>
+static hipError_t launch_fwd_h(const FwdArgs* a, hipStream_t st) {
+  const bool m = a->L > 1;
+  switch (a->mode) {
+    case PMG_FWD_DECODE:
+      return m ? launch_fwd_t<UPW, TPP, PMG_FWD_DECODE, true>(a, st) : launch_fwd_t<UPW, TPP, PMG_FWD_DECODE, false>(a, st);
+    case PMG_FWD_TEACHER:
+      return m ? launch_fwd_t<UPW, TPP, PMG_FWD_TEACHER, true>(a, st) : launch_fwd_t<UPW, TPP, PMG_FWD_TEACHER, false>(a, st);
+    case PMG_FWD_STEP:
+      return m ? launch_fwd_t<UPW, TPP, PMG_FWD_STEP, true>(a, st) : launch_fwd_t<UPW, TPP, PMG_FWD_STEP, false>(a, st);
+  }
+  return hipErrorInvalidValue;
+}
+
 hipError_t pmg_launch_fwd(const FwdArgs* a, hipStream_t st) {
   switch (a->H) {
-    case 128: return launch_fwd_t<1, 1>(a, st);
-    case 256: return launch_fwd_t<2, 2>(a, st);
-    case 512: return launch_fwd_t<4, 2>(a, st);
-    case 1024: return launch_fwd_t<8, 2>(a, st);
+    case 128: return launch_fwd_h<1, 1>(a, st);
+    case 256: return launch_fwd_h<2, 2>(a, st);
+    case 512: return launch_fwd_h<4, 2>(a, st);
+    case 1024: return launch_fwd_h<8, 2>(a, st);
   }
   return hipErrorInvalidValue;
 }
