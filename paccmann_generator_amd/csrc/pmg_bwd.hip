@@ -24,6 +24,10 @@ __device__ __forceinline__ f32x4 ld4(const float* p) {
 __device__ __forceinline__ void st4(float* p, const f32x4 v) {
   *reinterpret_cast<float4*>(p) = make_float4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ f32x4 bl4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const float4 v = pmg_bload(r, voff, soff);
+  f32x4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; return o;
+}
 
 // acc[t] += Wt[tile t][groups of this chunk] * chunk columns.  24 reduction groups:
 // 8 per piece; pcN = LDS column block (of 128) holding piece N of this product.
@@ -94,8 +98,8 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
   const int H = a.H, XP = a.XP, W = a.W, D = a.D, V = a.V, L = a.L, B = a.B, G = a.G, N = a.N;
   const int UT = H / 16, NXT = a.NXT;
   const int dbg = a.dbg;
-  float* cb = reinterpret_cast<float*>(smem);   // [2][16][PMG_CP]
-  float* dxl = cb + 2 * 16 * PMG_CP;            // [16][XP]   dctrl | dpush | dlogits
+  float* cb = reinterpret_cast<float*>(smem);   // [NCB][16][PMG_CP], NCB = min(H/128, 4)
+  float* dxl = cb + (UPW < 4 ? UPW : 4) * 16 * PMG_CP;            // [16][XP]   dctrl | dpush | dlogits
   float* dtl = dxl + 16 * XP;                   // [16][PMG_XTP] dtop
   float* red = dtl + 16 * PMG_XTP;              // [8][4][12]
   float* lsl = red + PMG_WAVES * 48;            // [16] loss terms
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
   if (tid < 16) myR = (row0 + tid < B) ? a.reward[row0 + tid] : 0.0f;
   __syncthreads();
 
-  int par = 0;  // chunk buffer parity, alternates on every chunk
+  constexpr int NCB = UPW < 4 ? UPW : 4;  // chunk buffers (and chunks per round)
   // PMG_DEBUG bit 0x8000: per-phase cycle counters of workgroup 0, printed at the end
   const bool prof = (dbg & 0x8000) != 0;
   long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -150,60 +154,79 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
           acc_hh[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
           acc_dx[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        const float* gt_base = a.GT[l] + (((size_t)p * G + g) * UT) * 1024;
-        const float* hh_base = a.HH[l] + (((size_t)p * G + g) * H) * 16;
-        float* dg_base = a.DG[l] + (((size_t)p * G + g) * 4 * H) * 16;
+        // history and gradient slabs of this (step, row group) through buffer resources: one
+        // lane-constant byte offset in a VGPR, everything else is a wave-uniform offset
+        const __amdgpu_buffer_rsrc_t gtr = pmg_rsrc(a.GT[l] + (((size_t)p * G + g) * UT) * 1024, (unsigned)H * 256u);
+        const __amdgpu_buffer_rsrc_t hhr = pmg_rsrc(a.HH[l] + (((size_t)p * G + g) * H) * 16, (unsigned)H * 64u);
+        const __amdgpu_buffer_rsrc_t dgr = pmg_rsrc(a.DG[l] + (((size_t)p * G + g) * 4 * H) * 16, (unsigned)H * 256u);
+        const unsigned vrow = (unsigned)((16 * wave * UPW + 4 * q) * 16 + b) * 4u;  // element (feature 4q of this wave's first tile, row b)
+        // The cell backward of NCB chunks (128 hidden units each) runs first, with every history
+        // load of the round in flight at once, into NCB chunk buffers; then one barrier and the
+        // products over all of them back to back (one long reduction, no barriers in between).
 #pragma unroll
-        for (int c = 0; c < UPW; ++c) {
-          // ---- GRU cell backward for unit tile c of this wave
-          const int ug = wave * UPW + c;
-          const int j0 = 16 * ug + 4 * q;
-          const float* gp = gt_base + (size_t)ug * 1024 + lane * 4;
-          const f32x4 r = pmg_ld4h<4>(gp), z = pmg_ld4h<4>(gp + 256), n = pmg_ld4h<4>(gp + 512), ghn = pmg_ld4h<4>(gp + 768);
-          f32x4 hp;
+        for (int rd = 0; rd < UPW / NCB; ++rd) {
+          if (rd > 0 || (MULTI && l < L - 1)) __syncthreads();  // chunk buffers free again
+          f32x4 hr[NCB], hz[NCB], hn[NCB], hg[NCB], hp[NCB];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) hp[j] = pmg_ld1h<4>(hh_base + (size_t)(j0 + j) * 16 + b);
-          const f32x4 d = dh[c];
-          f32x4 dr_pre, dz_pre, dn_pre, dghn;
+          for (int cc = 0; cc < NCB; ++cc) {
+            const unsigned c = (unsigned)(rd * NCB + cc);
+            const unsigned gs = ((unsigned)(wave * UPW) + c) * 4096u;  // bytes: tile * 1024 floats
+            hr[cc] = bl4(gtr, voff, gs); hz[cc] = bl4(gtr, voff, gs + 1024u); hn[cc] = bl4(gtr, voff, gs + 2048u);
+            hg[cc] = bl4(gtr, voff, gs + 3072u);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float dn = d[j] * (1.0f - z[j]);
-            const float dz = d[j] * (hp[j] - n[j]);
-            dn_pre[j] = dn * (1.0f - n[j] * n[j]);
-            const float dr = dn_pre[j] * ghn[j];
-            dghn[j] = dn_pre[j] * r[j];
-            dz_pre[j] = dz * z[j] * (1.0f - z[j]);
-            dr_pre[j] = dr * r[j] * (1.0f - r[j]);
+            for (int j = 0; j < 4; ++j)
+              hp[cc][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(hhr, vrow, (c * 256u + j * 16u) * 4u, 0));
           }
-          acc_hh[c] += d * z;
-          float* cbw = cb + (size_t)par * 16 * PMG_CP + b * PMG_CP + 16 * wave + 4 * q;
-          st4(cbw, dr_pre); st4(cbw + PMG_CHUNK, dz_pre); st4(cbw + 2 * PMG_CHUNK, dn_pre);
-          st4(cbw + 3 * PMG_CHUNK, dghn);
-          if (!(dbg & 0x1000))
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            pmg_st1h<8>(dg_base + ((size_t)(0 * H + j0 + j)) * 16 + b, dr_pre[j]);
-            pmg_st1h<8>(dg_base + ((size_t)(1 * H + j0 + j)) * 16 + b, dz_pre[j]);
-            pmg_st1h<8>(dg_base + ((size_t)(2 * H + j0 + j)) * 16 + b, dn_pre[j]);
-            pmg_st1h<8>(dg_base + ((size_t)(3 * H + j0 + j)) * 16 + b, dghn[j]);
+          for (int cc = 0; cc < NCB; ++cc) {
+            const int c = rd * NCB + cc;
+            const f32x4 r = hr[cc], z = hz[cc], n = hn[cc], ghn = hg[cc];
+            const f32x4 d = dh[c];
+            f32x4 dr_pre, dz_pre, dn_pre, dghn;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float dn = d[j] * (1.0f - z[j]);
+              const float dz = d[j] * (hp[cc][j] - n[j]);
+              dn_pre[j] = dn * (1.0f - n[j] * n[j]);
+              const float dr = dn_pre[j] * ghn[j];
+              dghn[j] = dn_pre[j] * r[j];
+              dz_pre[j] = dz * z[j] * (1.0f - z[j]);
+              dr_pre[j] = dr * r[j] * (1.0f - r[j]);
+            }
+            acc_hh[c] += d * z;
+            float* cbw = cb + (size_t)cc * 16 * PMG_CP + b * PMG_CP + 16 * wave + 4 * q;
+            st4(cbw, dr_pre); st4(cbw + PMG_CHUNK, dz_pre); st4(cbw + 2 * PMG_CHUNK, dn_pre);
+            st4(cbw + 3 * PMG_CHUNK, dghn);
+            if (!(dbg & 0x1000))
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const unsigned so = ((unsigned)c * 256u + j * 16u) * 4u, gH = (unsigned)H * 64u;
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dr_pre[j]), dgr, vrow, so, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz_pre[j]), dgr, vrow, so + gH, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dn_pre[j]), dgr, vrow, so + 2u * gH, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dghn[j]), dgr, vrow, so + 3u * gH, 0);
+            }
           }
           PMG_TICK(0)
           __syncthreads();
           PMG_TICK(1)
-          // ---- products over this chunk's 3*128 reduction rows
-          const float* xb = cb + (size_t)par * 16 * PMG_CP + b * PMG_CP + 4 * q;
-          {
-            const unsigned so = a.oWHHt[l] + ((unsigned)(wave * UPW) * KG3 + (unsigned)c * 24u) * 1024u;
-            if (!(dbg & 0x400)) gemm_chunk<UPW>(acc_hh, wrs, voff, so, KG3 * 1024u, xb, 0, 1, 3);
+#pragma unroll
+          for (int cc = 0; cc < NCB; ++cc) {
+            const int c = rd * NCB + cc;
+            // ---- products over this chunk's 3*128 reduction rows
+            const float* xb = cb + (size_t)cc * 16 * PMG_CP + b * PMG_CP + 4 * q;
+            {
+              const unsigned so = a.oWHHt[l] + ((unsigned)(wave * UPW) * KG3 + (unsigned)c * 24u) * 1024u;
+              if (!(dbg & 0x400)) gemm_chunk<UPW>(acc_hh, wrs, voff, so, KG3 * 1024u, xb, 0, 1, 3);
+            }
+            if (MULTI && l > 0) {
+              const unsigned so = a.oWIHt[l] + ((unsigned)(wave * UPW) * KG3 + (unsigned)c * 24u) * 1024u;
+              gemm_chunk<UPW>(acc_dx, wrs, voff, so, KG3 * 1024u, xb, 0, 1, 2);
+            } else if (wave < PMG_KS / 16) {
+              const unsigned so = a.oWIHt[0] + ((unsigned)wave * KG3 + (unsigned)c * 24u) * 1024u;
+              if (!(dbg & 0x800)) gemm_chunk<1>(acc_top, wrs, voff, so, KG3 * 1024u, xb, 0, 1, 2);
+            }
           }
-          if (MULTI && l > 0) {
-            const unsigned so = a.oWIHt[l] + ((unsigned)(wave * UPW) * KG3 + (unsigned)c * 24u) * 1024u;
-            gemm_chunk<UPW>(acc_dx, wrs, voff, so, KG3 * 1024u, xb, 0, 1, 2);
-          } else if (wave < PMG_KS / 16) {
-            const unsigned so = a.oWIHt[0] + ((unsigned)wave * KG3 + (unsigned)c * 24u) * 1024u;
-            if (!(dbg & 0x800)) gemm_chunk<1>(acc_top, wrs, voff, so, KG3 * 1024u, xb, 0, 1, 2);
-          }
-          par ^= 1;
           PMG_TICK(2)
         }
 #pragma unroll
@@ -395,7 +418,8 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
 }  // namespace
 
 size_t pmg_bwd_lds_bytes(const BwdArgs* a) {
-  return ((size_t)2 * 16 * PMG_CP + (size_t)16 * a->XP + 16 * PMG_XTP + PMG_WAVES * 48 + 16) * sizeof(float);
+  const size_t ncb = (a->H / 128 < 4) ? a->H / 128 : 4;
+  return (ncb * 16 * PMG_CP + (size_t)16 * a->XP + 16 * PMG_XTP + PMG_WAVES * 48 + 16) * sizeof(float);
 }
 
 template <int UPW, bool MULTI>
