@@ -42,6 +42,7 @@ struct WJob {
   int tile0;        // first tile index within its kernel variant's grid
   int rs0;          // offset of this job's row sums in the row-sum vector
   int P;            // time slabs
+  int S;            // split-K factor of the launch this job belongs to
   size_t c_off;     // offset of the dense C in the accumulator region
   size_t pt_off;    // offset of this job's first partial tile within one split's partial block
 };
@@ -82,8 +83,11 @@ __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArg
   // XCD-aware remap: blocks b and b+8 share an XCD; give each XCD a contiguous run of
   // virtual ids so that the tiles of one split (same slabs) meet in one L2.
   const int nblk = gridDim.x;  // multiple of 8
+  int jS = 1;
+  for (int k = 0; k < a.njobs; ++k)
+    if (a.jobs[k].tn == TN && a.jobs[k].mode == MODE) jS = a.jobs[k].S;
   const int v = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
-  if (v >= ntiles * a.S) return;
+  if (v >= ntiles * jS) return;
   const int s = v / ntiles;
   int t = v - s * ntiles;
   int ji = 0;
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArg
   const int H = a.H, G = a.G;
 
   const int nslab = jb.P * G;
-  const int per = (nslab + a.S - 1) / a.S;
+  const int per = (nslab + jb.S - 1) / jb.S;
   const int sl0 = s * per;
   const int sl1 = (sl0 + per < nslab) ? sl0 + per : nslab;
   const int ns = sl1 - sl0;
@@ -245,12 +249,15 @@ __global__ void pmg_wgrad_reduce_kernel(const WgradArgs a) {
       const int tl = (r / WG_TM) * jb.col_tiles + (c / jb.tn);
       const size_t e = jb.pt_off + (size_t)tl * (WG_TM * jb.tn) + (size_t)(r % WG_TM) * jb.tn + (c % jb.tn);
       float sum = 0.0f;
-      for (int s = 0; s < a.S; ++s) sum += a.partial[(size_t)s * a.split_stride + e];
+      for (int s = 0; s < jb.S; ++s) sum += a.partial[(size_t)s * a.split_stride + e];
       a.dense[jb.c_off + rem] = sum;
     } else {
       const size_t r = idx - total;
+      int jS = 1;
+      for (int k = 0; k < a.njobs; ++k)
+        if ((size_t)a.jobs[k].rs0 <= r && r < (size_t)(a.jobs[k].rs0 + a.jobs[k].rows)) jS = a.jobs[k].S;
       float sum = 0.0f;
-      for (int s = 0; s < a.S; ++s) sum += a.rs_partial[(size_t)s * a.total_rs + r];
+      for (int s = 0; s < jS; ++s) sum += a.rs_partial[(size_t)s * a.total_rs + r];
       a.dense[total + r] = sum;  // row sums live right after the dense matrices
     }
   }
@@ -369,11 +376,23 @@ struct JobPlan {
   size_t dense_floats, partial_floats, rs_partial_floats;
 };
 
-int choose_splits(const PmgDims& d, int total_tiles) {
+// Split-K factor of one launch with `tiles` output tiles.  512 blocks are resident at a time (two per
+// CU), so the grid should be close to a whole number of such rounds: take the factor whose last
+// round is fullest among those that give 1..4 rounds.
+int choose_splits(const PmgDims& d, int tiles) {
   const long slabs = (long)d.T * d.G;
-  long S = 2048 / (total_tiles > 0 ? total_tiles : 1);
-  if (S < 1) S = 1;
-  if (S > 64) S = 64;
+  if (tiles < 1) tiles = 1;
+  long best = 1;
+  double best_fill = -1.0;
+  for (long S = 1; S <= 64; ++S) {
+    const long blocks = S * tiles;
+    const long rounds = (blocks + 511) / 512;
+    if (rounds > 4 && S > 1) break;
+    const double fill = (double)blocks / (double)(rounds * 512);
+    // prefer fuller rounds; among equals the larger grid (shorter tail per block)
+    if (fill > best_fill + 1e-9 || (fill > best_fill - 1e-9 && S > best)) { best_fill = fill; best = S; }
+  }
+  long S = best;
   const long maxS = (slabs + 3) / 4;  // at least ~4 slabs per split
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
@@ -423,7 +442,17 @@ void build_plan(const PmgDims& d, JobPlan* P) {
   }
   { WJob& j = add(d.NXT * 16, H, d.NXT * 16, 0, H, 0, N + 1, WG_PLAIN); f.c_x = j.c_off; f.rs_x = j.rs0; }
   w.njobs = nj; w.tiles_wide = tile_w; w.tiles_narrow = tile_n; w.total_rs = rs;
-  w.S = choose_splits(d, tile_w + tile_n);
+  {
+    int cnt[2][3] = {{0, 0, 0}, {0, 0, 0}}, Sl[2][3];
+    for (int j = 0; j < nj; ++j) cnt[w.jobs[j].tn == 128][w.jobs[j].mode] += w.jobs[j].row_tiles * w.jobs[j].col_tiles;
+    w.S = 1;
+    for (int a2 = 0; a2 < 2; ++a2)
+      for (int m = 0; m < 3; ++m) {
+        Sl[a2][m] = cnt[a2][m] ? choose_splits(d, cnt[a2][m]) : 1;
+        if (Sl[a2][m] > w.S) w.S = Sl[a2][m];
+      }
+    for (int j = 0; j < nj; ++j) w.jobs[j].S = Sl[w.jobs[j].tn == 128][w.jobs[j].mode];
+  }
   w.split_stride = ptoff;
   w.G = d.G; w.B = d.B; w.H = H;
   // row sums are stored right behind the dense matrices
@@ -473,18 +502,21 @@ hipError_t pmg_run_wgrad(const PmgDims& d, const PmgLayout& lay, float* ws, cons
     int nt[2][3] = {{0, 0, 0}, {0, 0, 0}};  // [wide][mode]
     for (int j = 0; j < w.njobs; ++j)
       nt[w.jobs[j].tn == 128][w.jobs[j].mode] += w.jobs[j].row_tiles * w.jobs[j].col_tiles;
-#define PMG_WG_LAUNCH(cnt, ...)                                                              \
-  if ((cnt) > 0) {                                                                           \
-    const int nb = (((cnt) * w.S + 7) / 8) * 8;                                              \
+#define PMG_WG_LAUNCH(wide_, mode_, ...)                                                     \
+  if (nt[wide_][mode_] > 0) {                                                                \
+    int jS = 1;                                                                              \
+    for (int j = 0; j < w.njobs; ++j)                                                        \
+      if ((w.jobs[j].tn == 128) == (wide_ != 0) && w.jobs[j].mode == mode_) jS = w.jobs[j].S; \
+    const int nb = ((nt[wide_][mode_] * jS + 7) / 8) * 8;                                    \
     hipLaunchKernelGGL((pmg_wgrad_kernel<__VA_ARGS__>), dim3(nb), dim3(WG_THREADS), 0, st, w); \
     e = hipGetLastError();                                                                   \
     if (e != hipSuccess) return e;                                                           \
   }
-    PMG_WG_LAUNCH(nt[1][WG_PLAIN], 4, 4, 2, 2, WG_PLAIN)
-    PMG_WG_LAUNCH(nt[1][WG_MIXED], 4, 4, 2, 2, WG_MIXED)
-    PMG_WG_LAUNCH(nt[1][WG_ONEHOT], 4, 4, 2, 2, WG_ONEHOT)
-    PMG_WG_LAUNCH(nt[0][WG_PLAIN], 2, 4, 4, 1, WG_PLAIN)
-    PMG_WG_LAUNCH(nt[0][WG_ONEHOT], 2, 4, 4, 1, WG_ONEHOT)
+    PMG_WG_LAUNCH(1, WG_PLAIN, 4, 4, 2, 2, WG_PLAIN)
+    PMG_WG_LAUNCH(1, WG_MIXED, 4, 4, 2, 2, WG_MIXED)
+    PMG_WG_LAUNCH(1, WG_ONEHOT, 4, 4, 2, 2, WG_ONEHOT)
+    PMG_WG_LAUNCH(0, WG_PLAIN, 2, 4, 4, 1, WG_PLAIN)
+    PMG_WG_LAUNCH(0, WG_ONEHOT, 2, 4, 4, 1, WG_ONEHOT)
 #undef PMG_WG_LAUNCH
   }
   {
