@@ -31,13 +31,24 @@ def main():
         data[nm] = agg
     med = statistics.median
     rows = []
-    fw = [k for k in data['write'] if 'pmg_fwd' in k][0]
-    wv, fv = data['write'][fw], data['fetch'][fw]
-    thr = (min(wv) + max(wv)) / 2  # decode launches write the stack ping-pong only, teacher ones the history too
-    for name, idx in (('decode', [i for i, v in enumerate(wv) if v < thr]),
-                      ('teacher_fwd', [i for i, v in enumerate(wv) if v >= thr])):
-        rows.append((name, 'pmg_fwd_kernel (' + name + ')', len(idx), med([fv[i] for i in idx]),
-                     med([wv[i] for i in idx])))
+    # the forward kernel is instantiated per mode: pmg_fwd_kernel<UPW, TPP, MODE, MULTI>, MODE 0 = decode,
+    # 1 = teacher-forced (older builds: one instantiation, told apart by the bytes written)
+    fwd = [k for k in data['write'] if 'pmg_fwd' in k]
+    if len(fwd) > 1:
+        for k in fwd:
+            mode = int(k.split('<')[1].split(',')[2])
+            name = {0: 'decode', 1: 'teacher_fwd'}.get(mode)
+            if name:
+                rows.append((name, f'pmg_fwd_kernel ({name})', len(data['fetch'][k]), med(data['fetch'][k]),
+                             med(data['write'][k])))
+    else:
+        fw = fwd[0]
+        wv, fv = data['write'][fw], data['fetch'][fw]
+        thr = (min(wv) + max(wv)) / 2
+        for name, idx in (('decode', [i for i, v in enumerate(wv) if v < thr]),
+                          ('teacher_fwd', [i for i, v in enumerate(wv) if v >= thr])):
+            rows.append((name, 'pmg_fwd_kernel (' + name + ')', len(idx), med([fv[i] for i in idx]),
+                         med([wv[i] for i in idx])))
     wg_f = wg_w = 0.0
     for k in data['fetch']:
         if 'pmg_fwd' in k or 'pack' in k or 'aux' in k:
