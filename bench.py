@@ -40,9 +40,13 @@ CONFIGS = {
                  n_layers=1, latent_dim=256, pad_index=0, batch=4096, length=128),
     'cfg4': dict(embedding_size=128, rnn_cell_size=1024, vocab_size=60, stack_width=50, stack_depth=50,
                  n_layers=2, latent_dim=256, pad_index=0, batch=4096, length=256),
+    # configs[4]: teacher-forced log-prob + BPTT only, over pre-sampled sequences in chunks of `batch`
+    'cfg5': dict(embedding_size=128, rnn_cell_size=512, vocab_size=60, stack_width=50, stack_depth=50,
+                 n_layers=1, latent_dim=256, pad_index=0, batch=4096, length=128),
 }
 KIND = {'cfg1': 'omics-conditioned (reinforce_omics path)', 'cfg2': 'omics-conditioned',
-        'cfg4': 'protein-conditioned (reinforce_proteins path)'}
+        'cfg4': 'protein-conditioned (reinforce_proteins path)',
+        'cfg5': '1M-class pre-sampled sequences, teacher-forced log-prob + BPTT only,'}
 START, STOP = 2, 3
 
 
@@ -116,6 +120,17 @@ def cpu_baseline(cfg, budget_s=20.0):
     return dict(value=B * T * n / el, unit='tokens/s', cores=torch.get_num_threads(), kind='port',
                 sample=f'{n} decode+REINFORCE steps of the eager-PyTorch oracle at B={B}, T={T} '
                        f'(same model shape), {el:.1f}s')
+
+
+def presampled_tokens(n, T, V, device, seed=5):
+    """uniform random tokens in [4,V), length ~U[20, T-2], then stop, stop, pad.
+    Returns [T+2, n] int64 (pad_sequence layout)."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    lens = torch.randint(20, T - 1, (n,), generator=g)
+    body = torch.randint(4, V, (T + 2, n), generator=g)
+    pos = torch.arange(T + 2).unsqueeze(1)
+    toks = torch.where(pos < lens, body, torch.where(pos < lens + 2, torch.full_like(body, STOP), torch.zeros_like(body)))
+    return toks.to(device)
 
 
 def pmc_traffic(config, B, kernel):
@@ -201,6 +216,7 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-phases', action='store_true')
+    ap.add_argument('--seqs', type=int, default=65536, help='cfg5: pre-sampled sequences per step (1M = 1048576)')
     args = ap.parse_args()
     if os.environ.get('PMG_HANG_DUMP'):  # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
@@ -245,6 +261,28 @@ def main():
         padded = pad_rows_on_device(tokens, lens, STOP, t_max=T + 2)
         learner.learn(latent, padded, valid_idx, rewards, lrps=1, n_valid_global=B * world)
 
+    tokens_per_step = B * T
+    if args.config == 'cfg5':
+        # one step = one pass of teacher-forced log-probs + BPTT + weight gradients over args.seqs
+        # pre-sampled sequences per GPU, in chunks of B whose gradients accumulate; one update at the end
+        from paccmann_generator_amd import ops
+        n_chunks = max(1, args.seqs // B)
+        chunks = [presampled_tokens(B, T, cfg['vocab_size'], device, seed=5 + rank * 1000 + c) for c in range(min(n_chunks, 8))]
+        dec = learner.generator.decoder
+        tokens_per_step = n_chunks * B * T
+
+        def step():  # noqa: F811
+            learner.optimizer.zero_grad()
+            for c in range(n_chunks):
+                h0 = dec.latent_to_hidden(latent.repeat(dec.n_layers, 1, 1))
+                loss, _ = ops.reinforce_loss(dec.weights(), chunks[c % len(chunks)], h0, rewards,
+                                             1.0 / (n_chunks * B * world))
+                loss.backward()
+            if world > 1:
+                dp.all_reduce_gradients_(dec.parameters())
+            torch.nn.utils.clip_grad_norm_(list(dec.parameters()), 0.1)
+            learner.optimizer.step()
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -265,20 +303,22 @@ def main():
         el = float(t.item())
 
     ms_per_step = 1e3 * el / args.steps
-    tokens_per_s = world * B * T * args.steps / el
+    tokens_per_s = world * tokens_per_step * args.steps / el
     F = flops_per_token(cfg)
 
     result = {
-        'metric': 'sampled SMILES tokens/sec (decode + REINFORCE step)',
+        'metric': ('SMILES tokens/sec (teacher-forced log-prob + BPTT step over pre-sampled sequences)'
+                   if args.config == 'cfg5' else 'sampled SMILES tokens/sec (decode + REINFORCE step)'),
         'value': tokens_per_s, 'unit': 'tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'{args.config}: {KIND[args.config]} decode+REINFORCE, hidden {cfg["rnn_cell_size"]}, '
+        'config': {'workload': f'{args.config}: {KIND[args.config]}{'' if args.config == 'cfg5' else ' decode+REINFORCE,'} hidden {cfg["rnn_cell_size"]}, '
                                f'stack {cfg["stack_depth"]}x{cfg["stack_width"]}, layers {cfg["n_layers"]}, '
                                f'vocab {cfg["vocab_size"]}, emb {cfg["embedding_size"]}, latent {cfg["latent_dim"]}',
                    'batch_per_gpu': B, 'global_batch': B * world, 'len': T, 'parallelism': f'dp{world}',
                    'flop_per_token_fwd': F},
         'step_roofline_frac': (tokens_per_s / world) * 3 * F / (PEAK_F32_MFMA_TFLOPS * 1e12),
+        'tokens_per_step_per_gpu': tokens_per_step,
     }
     if rank == 0:
         if not args.no_phases:

@@ -38,6 +38,9 @@ __device__ __forceinline__ void st4(float* p, const f32x4 v) {
 // requested after the side job's store also waits for that store's acknowledgement: the side job
 // sits right after the loads of the second half group, which gives its store two half groups of
 // MFMAs before the next wait that covers it.
+#ifndef PMG_STACK_THREADS
+#define PMG_STACK_THREADS 512
+#endif
 struct NoSide {
   static constexpr bool kActive = false;
   template <int U> __device__ __forceinline__ void step() const {}
@@ -292,7 +295,11 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
   size_t st_cofs;
   {
     const int ncol = W * 4;  // <= 256 (pmg_check_shape caps W at 64): one item per thread
-    st_dsplit = PMG_THREADS / ncol;
+    // PMG_STACK_THREADS: threads that take part in the stack update.  Restricting it to waves 0-3
+    // (which the issue arbiter favours, so they finish the W_hh product early) was measured and
+    // was slower: waves 4-7 do not speed up when relieved of the side job.
+    st_dsplit = PMG_STACK_THREADS / ncol;
+    if (st_dsplit < 1) st_dsplit = 1;
     if (st_dsplit > D) st_dsplit = D;
     st_bq = tid & 3;
     const int cw = tid >> 2;
