@@ -47,6 +47,7 @@ CONFIGS = {
 KIND = {'cfg1': 'omics-conditioned (reinforce_omics path)', 'cfg2': 'omics-conditioned',
         'cfg4': 'protein-conditioned (reinforce_proteins path)',
         'cfg5': '1M-class pre-sampled sequences, teacher-forced log-prob + BPTT only,'}
+TAIL = {True: '', False: ' decode+REINFORCE,'}
 START, STOP = 2, 3
 
 
@@ -312,7 +313,7 @@ def main():
         'value': tokens_per_s, 'unit': 'tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'{args.config}: {KIND[args.config]}{'' if args.config == 'cfg5' else ' decode+REINFORCE,'} hidden {cfg["rnn_cell_size"]}, '
+        'config': {'workload': f'{args.config}: {KIND[args.config]}{TAIL[args.config == "cfg5"]} hidden {cfg["rnn_cell_size"]}, '
                                f'stack {cfg["stack_depth"]}x{cfg["stack_width"]}, layers {cfg["n_layers"]}, '
                                f'vocab {cfg["vocab_size"]}, emb {cfg["embedding_size"]}, latent {cfg["latent_dim"]}',
                    'batch_per_gpu': B, 'global_batch': B * world, 'len': T, 'parallelism': f'dp{world}',
