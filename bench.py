@@ -90,7 +90,7 @@ def build_learner(cfg, device, process_group=None):
     return learner
 
 
-def cpu_baseline(cfg, budget_s=20.0):
+def cpu_baseline(cfg, budget_s=12.0):
     """The CPU oracle driven through the reference's loop structure (generate +
     policy_gradient), on a bounded sample of the same workload."""
     from oracle import reinforce_loop as RL
@@ -116,7 +116,7 @@ def cpu_baseline(cfg, budget_s=20.0):
         one()
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 10:
+        if el > budget_s or n >= 60:
             break
     return dict(value=B * T * n / el, unit='tokens/s', cores=torch.get_num_threads(), kind='port',
                 sample=f'{n} decode+REINFORCE steps of the eager-PyTorch oracle at B={B}, T={T} '

@@ -130,11 +130,15 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
   __syncthreads();
 
   constexpr int NCB = UPW < 4 ? UPW : 4;  // chunk buffers (and chunks per round)
-  // PMG_DEBUG bit 0x8000: per-phase cycle counters of workgroup 0, printed at the end
+#ifdef PMG_PROFILE
+  // -DPMG_PROFILE build + PMG_DEBUG bit 0x8000: per-phase cycle counters of workgroup 0, printed at the end
   const bool prof = (dbg & 0x8000) != 0;
   long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #define PMG_TICK(k) if (prof) { const long long tn_ = (long long)__builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; }
+#else
+#define PMG_TICK(k)
+#endif
 
   // p == N is the virtual step that only injects dlogits_{N-1}
   for (int p = N; p >= 0; --p) {
@@ -394,9 +398,11 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
     __syncthreads();  // dxl / dtl / red reusable
     PMG_TICK(7)
   }
+#ifdef PMG_PROFILE
   if (prof && g == 0 && (tid & 63) == 0)
-    printf("bwd wave %d cycles(100MHz): cell %lld sync %lld gemm %lld sync2 %lld stack %lld dlogits+ctrl %lld extras %lld sync3 %lld\n", wave,
+    printf("bwd wave %d cycles: cell %lld sync %lld gemm %lld sync2 %lld stack %lld dlogits+ctrl %lld extras %lld sync3 %lld\n", wave,
            tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7]);
+#endif
 
   // ---------------------------------------------------------------- outputs
   for (int l = 0; l < L; ++l)

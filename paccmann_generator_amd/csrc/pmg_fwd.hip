@@ -311,11 +311,15 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   NoSide no_side;
 
-  // PMG_DEBUG bit 0x8000: per-phase cycle counters of workgroup 0, printed at the end
+#ifdef PMG_PROFILE
+  // -DPMG_PROFILE build + PMG_DEBUG bit 0x8000: per-phase cycle counters of workgroup 0, printed at the end
   const bool prof = (dbg & 0x8000) != 0;
   long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #define PMG_TICK(k) if (prof) { const long long tn_ = (long long)__builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; }
+#else
+#define PMG_TICK(k)
+#endif
 
   for (int i = 0;; ++i) {
     // ------------------------------------------------------------ stack: first rows requested early
@@ -616,9 +620,11 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     }
   }
 
+#ifdef PMG_PROFILE
   if (prof && g == 0 && lane == 0)
     printf("fwd wave %d cycles: extras %lld syncB1 %lld logits %lld gh+stack %lld syncB2 %lld top+gates %lld syncB3 %lld\n", wave,
            tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6]);
+#endif
   // ---------------------------------------------------------------- epilogue
   if (decode && (lane & 31) == 0 && row0 + cs_bb < B) a.len_out[row0 + cs_bb] = mylen;
   if (a.h_out != nullptr) {
