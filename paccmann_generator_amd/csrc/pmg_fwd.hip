@@ -24,6 +24,20 @@ __device__ __forceinline__ f32x4 ld4(const float* p) {
 __device__ __forceinline__ void st4(float* p, const f32x4 v) {
   *reinterpret_cast<float4*>(p) = make_float4(v.x, v.y, v.z, v.w);
 }
+// 16-byte accesses through a buffer resource: one lane-constant byte offset in a VGPR, everything
+// else wave-uniform (no 64-bit address arithmetic in vector registers)
+__device__ __forceinline__ f32x4 bl4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const float4 v = pmg_bload(r, voff, soff);
+  f32x4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; return o;
+}
+__device__ __forceinline__ void bs4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const f32x4 v) {
+  pmg_u32x4 u;
+  u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
+}
+__device__ __forceinline__ void bs1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
 
 // acc{r,z,t}[u0..u0+TPP) += W[tiles 3*u0 ..] * X   over KG groups of 16 columns.
 // Weights come through the buffer resource `rs`: voff = lane*16, soff = byte offset of
@@ -52,11 +66,12 @@ struct NoSide {
 // unconditional at a clamped row and masked when consumed (rows beyond old_hi read as zero).
 struct StackSide {
   static constexpr bool kActive = true;
-  const float* Sold; float* Snew;
+  __amdgpu_buffer_rsrc_t Sold, Snew;  // old / new stack slab of this row group
+  unsigned vcol;                      // byte offset of this thread's column inside a stack row
   f32x4 anoop, apush, apop, s_prev, s_cur, q[4];
   int d0, rows, old_hi, Dm1, sj, dch;  // dch: calls after which every thread of the workgroup is done
   unsigned rstr;  // floats per stack row slab line: W*16
-  bool on, nt;
+  bool on;
   template <int U> __device__ __forceinline__ void step() {
     if (sj >= dch) return;  // uniform: nothing left for anybody
     const int d = d0 + sj;
@@ -64,14 +79,13 @@ struct StackSide {
     if (sj + 4 < dch) {  // uniform: somebody will consume this slot again
       const int dn = d + 5;
       const int dc = dn < Dm1 ? dn : Dm1;
-      q[U] = *reinterpret_cast<const f32x4*>(Sold + (size_t)dc * rstr);
+      q[U] = bl4(Sold, (unsigned)dc * rstr * 4u + vcol, 0u);
     }
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     nxt = (d + 1 <= old_hi) ? nxt : z4;
     const f32x4 nw = anoop * s_cur + apush * s_prev + apop * nxt;
     if (on && sj < rows) {
-      if (nt) pmg_st4h<2>(Snew + (size_t)d * rstr, nw);
-      else *reinterpret_cast<f32x4*>(Snew + (size_t)d * rstr) = nw;
+      bs4(Snew, (unsigned)d * rstr * 4u + vcol, 0u, nw);
     }
     s_prev = s_cur;
     s_cur = nxt;
@@ -310,6 +324,10 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
   }
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   NoSide no_side;
+  const __amdgpu_buffer_rsrc_t bgr0 = pmg_rsrc(a.BG[0], (unsigned)H * 16u);
+  const __amdgpu_buffer_rsrc_t gtr = pmg_rsrc(a.GTAB, (unsigned)V * 3u * (unsigned)H * 4u);
+  const unsigned vq = 4u * q * 4u;                       // feature 4q of a 16-feature tile
+  const unsigned vrow = (unsigned)(4 * q * 16 + b) * 4u;  // (feature 4q, row b) of a [feature][16] slab
 
 #ifdef PMG_PROFILE
   // -DPMG_PROFILE build + PMG_DEBUG bit 0x8000: per-phase cycle counters of workgroup 0, printed at the end
@@ -325,7 +343,8 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     // ------------------------------------------------------------ stack: first rows requested early
     const int st_slot_old = teacher ? i : (i & 1);
     const int st_slot_new = teacher ? i + 1 : ((i + 1) & 1);
-    const float* const st_Sold = a.SB + ((size_t)st_slot_old * G + g) * a.SW + st_cofs;
+    const __amdgpu_buffer_rsrc_t st_Sold = pmg_rsrc(a.SB + ((size_t)st_slot_old * G + g) * a.SW, (unsigned)a.SW * 4u);
+    const unsigned st_vcol = (unsigned)st_cofs * 4u;
     // Live rows.  Entering step i only rows 0..i-1 of a stack that started at zero can be non-zero,
     // and row d of the new stack can reach the stack top (the only way the stack is ever read) no
     // earlier than step i+d: rows beyond min(i, N-1-i) are neither computed nor stored, and rows
@@ -350,18 +369,19 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     // old rows d0-1, d0, d0+1 (first row of this thread) and the ring d0+2 .. d0+5: requested here,
     // unconditionally at clamped rows (inactive threads read row 0 of their column), masked when used
     StackSide stk;
-    stk.Sold = st_Sold; stk.rstr = (unsigned)W * 16u; stk.Dm1 = D - 1;
-    stk.d0 = st_on ? st_d0 : 0; stk.dch = st_dch; stk.rows = st_rows; stk.old_hi = st_old_hi; stk.on = st_on; stk.nt = keep;
+    stk.Sold = st_Sold; stk.vcol = st_vcol; stk.rstr = (unsigned)W * 16u; stk.Dm1 = D - 1;
+    stk.d0 = st_on ? st_d0 : 0; stk.dch = st_dch; stk.rows = st_rows; stk.old_hi = st_old_hi; stk.on = st_on;
     f32x4 st_pm = zero4, st_c0 = zero4, st_n0 = zero4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) stk.q[j] = zero4;
     if (st_on) {  // only rows that hold data are requested (memory operations are not free here)
-      if (st_d0 > 0 && st_d0 - 1 <= st_old_hi) st_pm = ld4(st_Sold + (size_t)(st_d0 - 1) * stk.rstr);
-      if (st_d0 <= st_old_hi) st_c0 = ld4(st_Sold + (size_t)st_d0 * stk.rstr);
-      if (st_d0 + 1 <= st_old_hi) st_n0 = ld4(st_Sold + (size_t)(st_d0 + 1) * stk.rstr);
+      const unsigned rb = stk.rstr * 4u;
+      if (st_d0 > 0 && st_d0 - 1 <= st_old_hi) st_pm = bl4(st_Sold, (unsigned)(st_d0 - 1) * rb + st_vcol, 0u);
+      if (st_d0 <= st_old_hi) st_c0 = bl4(st_Sold, (unsigned)st_d0 * rb + st_vcol, 0u);
+      if (st_d0 + 1 <= st_old_hi) st_n0 = bl4(st_Sold, (unsigned)(st_d0 + 1) * rb + st_vcol, 0u);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (st_d0 + 2 + j <= st_old_hi && j + 1 < st_dch) stk.q[j] = ld4(st_Sold + (size_t)(st_d0 + 2 + j) * stk.rstr);
+        if (st_d0 + 2 + j <= st_old_hi && j + 1 < st_dch) stk.q[j] = bl4(st_Sold, (unsigned)(st_d0 + 2 + j) * rb + st_vcol, 0u);
     }
 
     // ------------------------------------------------------------ extras GEMM
@@ -474,7 +494,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     // Each thread walks its depth range one row per side-job call; rows d0-1 .. d0+3 were
     // requested before the extras GEMM, every call requests row d+4.
     f32x4 apush = zero4, apop = zero4, anoop = zero4, pv = zero4;
-    float* const st_Snew = a.SB + ((size_t)st_slot_new * G + g) * a.SW + st_cofs;
+    const __amdgpu_buffer_rsrc_t st_Snew = pmg_rsrc(a.SB + ((size_t)st_slot_new * G + g) * a.SW, (unsigned)a.SW * 4u);
     if (st_on) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -505,8 +525,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
       const f32x4 n0 = (st_d0 + 1 <= st_old_hi) ? st_n0 : zero4;
       if (st_on) {
         const f32x4 nw = anoop * c0 + apush * pm + apop * n0;
-        if (keep) pmg_st4h<2>(st_Snew + (size_t)st_d0 * stk.rstr, nw);
-        else st4(st_Snew + (size_t)st_d0 * stk.rstr, nw);
+        bs4(st_Snew, (unsigned)st_d0 * stk.rstr * 4u + st_vcol, 0u, nw);
         if (st_d0 == 0) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) xtop[(4 * st_bq + j) * PMG_XTP + st_w] = nw[j];
@@ -517,14 +536,19 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
       stk.s_cur = n0;
     }
 
+    // history slabs of this step (teacher mode) through buffer resources
+    __amdgpu_buffer_rsrc_t gth0 = wrs, hhh0 = wrs;
+    if (keep) {
+      gth0 = pmg_rsrc(a.GT[0] + (((size_t)i * G + g) * UT) * 1024, (unsigned)H * 256u);
+      hhh0 = pmg_rsrc(a.HH[0] + (((size_t)(i + 1) * G + g) * H) * 16, (unsigned)H * 64u);
+    }
     // ------------------------------------------------------------ layer 0: gh GEMM
 #pragma unroll
     for (int u = 0; u < UPW; ++u) {
-      const int j0 = 16 * (wave * UPW + u) + 4 * q;
-      ar[u] = ld4(a.BG[0] + 0 * H + j0);
-      az[u] = ld4(a.BG[0] + 1 * H + j0);
-      ai[u] = ld4(a.BG[0] + 2 * H + j0);
-      ah[u] = ld4(a.BG[0] + 3 * H + j0);
+      const unsigned so = (unsigned)(16 * (wave * UPW + u)) * 4u, gH = (unsigned)H * 4u;
+      ar[u] = bl4(bgr0, vq, so);
+      az[u] = bl4(bgr0, vq, so + gH);
+      ah[u] = bl4(bgr0, vq, so + 3u * gH);
     }
     if (!(dbg & 0x400)) gemm3<UPW, TPP>(ar, az, ah, wrs, voff, a.oWHH[0], KGH, h_lds + (size_t)b * HP + 4 * q, wave, stk);
     while (stk.sj < st_dch) {  // rows the GEMM loop did not reach (four calls keep the ring slots aligned)
@@ -544,19 +568,21 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     }
 
     // ------------------------------------------------------------ layer 0: stack-top GEMM, table, gates
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) ai[u] = bl4(bgr0, vq, (unsigned)(16 * (wave * UPW + u) + 2 * H) * 4u);
     if (!(dbg & 0x800)) gemm3<UPW, TPP>(ar, az, ai, wrs, voff, a.oWIH[0], PMG_KS / 16, xtop + b * PMG_XTP + 4 * q, wave, no_side);
     {
-      const int tok = misc[b];
-      const float* gt = a.GTAB + (size_t)tok * 3 * H;
+      const unsigned vtok = ((unsigned)misc[b] * 3u * (unsigned)H + 4u * q) * 4u;  // this row's table line
 #pragma unroll
       for (int u = 0; u < UPW; ++u) {
         const int ug = wave * UPW + u;
         const int j0 = 16 * ug + 4 * q;
         float* hp_ptr = &h_lds[(size_t)b * HP + j0];
         const f32x4 hp = ld4(hp_ptr);
-        const f32x4 vr = ar[u] + ld4(gt + j0);
-        const f32x4 vz = az[u] + ld4(gt + H + j0);
-        const f32x4 vi = ai[u] + ld4(gt + 2 * H + j0);
+        const unsigned so = (unsigned)(16 * ug) * 4u, gH = (unsigned)H * 4u;
+        const f32x4 vr = ar[u] + bl4(gtr, vtok, so);
+        const f32x4 vz = az[u] + bl4(gtr, vtok, so + gH);
+        const f32x4 vi = ai[u] + bl4(gtr, vtok, so + 2u * gH);
         const f32x4 vh = ah[u];
         f32x4 r, z, n, hn;
 #pragma unroll
@@ -568,11 +594,10 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
         }
         st4(hp_ptr, hn);
         if (keep) {
-          float* gp = a.GT[0] + ((((size_t)i * G + g) * UT + ug) * 4) * 256 + lane * 4;
-          pmg_st4h<1>(gp, r); pmg_st4h<1>(gp + 256, z); pmg_st4h<1>(gp + 512, n); pmg_st4h<1>(gp + 768, vh);
-          float* hh = a.HH[0] + (((size_t)(i + 1) * G + g) * H + j0) * 16 + b;
+          const unsigned gs = (unsigned)ug * 4096u;
+          bs4(gth0, voff, gs, r); bs4(gth0, voff, gs + 1024u, z); bs4(gth0, voff, gs + 2048u, n); bs4(gth0, voff, gs + 3072u, vh);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) pmg_st1h<1>(hh + j * 16, hn[j]);
+          for (int j = 0; j < 4; ++j) bs1(hhh0, vrow, (unsigned)((16 * ug + j) * 16) * 4u, hn[j]);
         }
       }
     }
