@@ -63,6 +63,17 @@ def test_train_parity_cfg2_shape_small_batch(gpu):
     P.check_train(P.CFG2, B=48, T=40, tol=TOL)
 
 
+def test_train_parity_cfg2_full_length(gpu):
+    """configs[1] model shape at its full length (T = 128 + 2 > 2 * stack depth): every regime of the
+    live-row logic of the stack (rows still zero, all rows live, rows already dead) is crossed."""
+    P.check_train(P.CFG2, B=18, T=130, tol=TOL)
+
+
+def test_greedy_exact_cfg2_full_length(gpu):
+    r = P.check_greedy(P.CFG2, 24, 128)
+    assert r['mismatched_rows'] == 0
+
+
 def test_train_parity_cfg4_shape_small_batch(gpu):
     """configs[3] model shape (2 layers, hidden 1024)."""
     P.check_train(P.CFG4, B=20, T=12, tol=TOL)
