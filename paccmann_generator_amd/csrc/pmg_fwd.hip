@@ -35,6 +35,23 @@ __device__ __forceinline__ void bs4(__amdgpu_buffer_rsrc_t r, unsigned voff, uns
   u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
   __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
 }
+// stack slab streams: cache-policy bits of the buffer instruction (bit 1 = nt) as a tuning knob
+#ifndef PMG_STACK_AUX_LD
+#define PMG_STACK_AUX_LD 0
+#endif
+#ifndef PMG_STACK_AUX_ST
+#define PMG_STACK_AUX_ST 0
+#endif
+__device__ __forceinline__ f32x4 bl4s(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  const pmg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, PMG_STACK_AUX_LD);
+  f32x4 o; o.x = __uint_as_float(v.x); o.y = __uint_as_float(v.y); o.z = __uint_as_float(v.z); o.w = __uint_as_float(v.w);
+  return o;
+}
+__device__ __forceinline__ void bs4s(__amdgpu_buffer_rsrc_t r, unsigned voff, const f32x4 v) {
+  pmg_u32x4 u;
+  u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, 0, PMG_STACK_AUX_ST);
+}
 __device__ __forceinline__ void bs1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
 }
@@ -79,13 +96,13 @@ struct StackSide {
     if (sj + 4 < dch) {  // uniform: somebody will consume this slot again
       const int dn = d + 5;
       const int dc = dn < Dm1 ? dn : Dm1;
-      q[U] = bl4(Sold, (unsigned)dc * rstr * 4u + vcol, 0u);
+      q[U] = bl4s(Sold, (unsigned)dc * rstr * 4u + vcol);
     }
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     nxt = (d + 1 <= old_hi) ? nxt : z4;
     const f32x4 nw = anoop * s_cur + apush * s_prev + apop * nxt;
     if (on && sj < rows) {
-      bs4(Snew, (unsigned)d * rstr * 4u + vcol, 0u, nw);
+      bs4s(Snew, (unsigned)d * rstr * 4u + vcol, nw);
     }
     s_prev = s_cur;
     s_cur = nxt;
@@ -219,8 +236,11 @@ __device__ __forceinline__ float fast_tanh(float x) {
 
 // MODE (decode / teacher / step) and MULTI (more than one layer) are compile-time: each variant
 // carries only the registers and branches it needs.
-template <int UPW, int TPP, int MODE, bool MULTI>
-__global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a) {
+// WV waves per workgroup (8 or 16): with 16 the kernel has to fit in 128 VGPRs, and four waves per
+// SIMD are there to fill each other's stalls.
+template <int WV, int UPW, int TPP, int MODE, bool MULTI>
+__global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs a) {
+  constexpr int NTHR = WV * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int H = a.H, HP = a.HP, XP = a.XP, W = a.W, D = a.D, V = a.V, L = a.L, B = a.B, G = a.G, N = a.N;
   const int KGH = a.KGH, UT = H / 16;
@@ -245,23 +265,23 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
   const int dbg = a.dbg;
 
   // ---------------------------------------------------------------- init
-  for (int idx = tid; idx < 16 * PMG_XTP; idx += PMG_THREADS) xtop[idx] = 0.0f;
+  for (int idx = tid; idx < 16 * PMG_XTP; idx += NTHR) xtop[idx] = 0.0f;
   if (tid < 32) misc[tid] = 0;
   if (decode) {
     // h0 = latent_to_hidden(latent): same value for every layer (reinforce.py:160-170 path)
     const int ZP = a.Z + 8;
-    for (int idx = tid; idx < 16 * a.Z; idx += PMG_THREADS) {
+    for (int idx = tid; idx < 16 * a.Z; idx += NTHR) {
       const int bb = idx / a.Z, k = idx - bb * a.Z;
       lat[bb * ZP + k] = (row0 + bb < B) ? a.latent[(size_t)(row0 + bb) * a.Z + k] : 0.0f;
     }
     __syncthreads();
-    for (int t = wave; t < UT; t += PMG_WAVES) {
+    for (int t = wave; t < UT; t += WV) {
       f32x4 acc = ld4(a.b_l2h + 16 * t + 4 * q);
       acc = gemm1(acc, wrs, voff, a.oL2H + (unsigned)t * (unsigned)(a.Z / 16) * 1024u, a.Z / 16, lat + b * ZP + 4 * q);
       for (int l = 0; l < L; ++l) st4(&h_lds[(size_t)(l * 16 + b) * HP + 16 * t + 4 * q], acc);
     }
   } else {
-    for (int idx = tid; idx < L * 16 * H; idx += PMG_THREADS) {
+    for (int idx = tid; idx < L * 16 * H; idx += NTHR) {
       const int l = idx / (16 * H);
       const int rem = idx - l * 16 * H;
       const int bb = rem / H, k = rem - bb * H;
@@ -278,7 +298,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
   if (stepm && a.stack_in != nullptr) {
     s_zero = false;
     float* S0 = a.SB + (size_t)g * a.SW;
-    for (int idx = tid; idx < D * W * 16; idx += PMG_THREADS) {
+    for (int idx = tid; idx < D * W * 16; idx += NTHR) {
       const int bb = idx & 15;
       const int dw = idx >> 4;
       S0[idx] = (row0 + bb < B) ? a.stack_in[(size_t)(row0 + bb) * D * W + dw] : 0.0f;
@@ -286,7 +306,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
   }
   __syncthreads();
   if (keep) {
-    for (int idx = tid; idx < L * 16 * H; idx += PMG_THREADS) {
+    for (int idx = tid; idx < L * 16 * H; idx += NTHR) {
       const int l = idx / (16 * H);
       const int rem = idx - l * 16 * H;
       const int k = rem >> 4, bb = rem & 15;
@@ -295,7 +315,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
   }
 
   // logits are consumed by every wave: rows 2*wave and 2*wave+1, 32 lanes per row
-  const int cs_bb = 2 * wave + (lane >> 5);
+  const int cs_bb = (WV == 8) ? 2 * wave + (lane >> 5) : wave;  // 16 waves: both halves of a wave do the same row
   // sampling state of row cs_bb (identical in the 32 lanes of the row)
   bool finished = false;
   int mylen = N;
@@ -312,7 +332,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     // PMG_STACK_THREADS: threads that take part in the stack update.  Restricting it to waves 0-3
     // (which the issue arbiter favours, so they finish the W_hh product early) was measured and
     // was slower: waves 4-7 do not speed up when relieved of the side job.
-    st_dsplit = PMG_STACK_THREADS / ncol;
+    st_dsplit = (PMG_STACK_THREADS < NTHR ? PMG_STACK_THREADS : NTHR) / ncol;
     if (st_dsplit < 1) st_dsplit = 1;
     if (st_dsplit > D) st_dsplit = D;
     st_bq = tid & 3;
@@ -376,18 +396,18 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     for (int j = 0; j < 4; ++j) stk.q[j] = zero4;
     if (st_on) {  // only rows that hold data are requested (memory operations are not free here)
       const unsigned rb = stk.rstr * 4u;
-      if (st_d0 > 0 && st_d0 - 1 <= st_old_hi) st_pm = bl4(st_Sold, (unsigned)(st_d0 - 1) * rb + st_vcol, 0u);
-      if (st_d0 <= st_old_hi) st_c0 = bl4(st_Sold, (unsigned)st_d0 * rb + st_vcol, 0u);
-      if (st_d0 + 1 <= st_old_hi) st_n0 = bl4(st_Sold, (unsigned)(st_d0 + 1) * rb + st_vcol, 0u);
+      if (st_d0 > 0 && st_d0 - 1 <= st_old_hi) st_pm = bl4s(st_Sold, (unsigned)(st_d0 - 1) * rb + st_vcol);
+      if (st_d0 <= st_old_hi) st_c0 = bl4s(st_Sold, (unsigned)st_d0 * rb + st_vcol);
+      if (st_d0 + 1 <= st_old_hi) st_n0 = bl4s(st_Sold, (unsigned)(st_d0 + 1) * rb + st_vcol);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (st_d0 + 2 + j <= st_old_hi && j + 1 < st_dch) stk.q[j] = bl4(st_Sold, (unsigned)(st_d0 + 2 + j) * rb + st_vcol, 0u);
+        if (st_d0 + 2 + j <= st_old_hi && j + 1 < st_dch) stk.q[j] = bl4s(st_Sold, (unsigned)(st_d0 + 2 + j) * rb + st_vcol);
     }
 
     // ------------------------------------------------------------ extras GEMM
     if (!(dbg & 0x200)) {
       const float* xrow = h_lds + (size_t)((L - 1) * 16 + b) * HP + 4 * q;
-      for (int xt = wave; xt < a.NXT; xt += PMG_WAVES) {
+      for (int xt = wave; xt < a.NXT; xt += WV) {
         f32x4 acc = ld4(a.BX + 16 * xt + 4 * q);
         acc = gemm1(acc, wrs, voff, a.oWX + (unsigned)xt * (unsigned)KGH * 1024u, KGH, xrow);
         st4(&xex[b * XP + 16 * xt + 4 * q], acc);
@@ -525,7 +545,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
       const f32x4 n0 = (st_d0 + 1 <= st_old_hi) ? st_n0 : zero4;
       if (st_on) {
         const f32x4 nw = anoop * c0 + apush * pm + apop * n0;
-        bs4(st_Snew, (unsigned)st_d0 * stk.rstr * 4u + st_vcol, 0u, nw);
+        bs4s(st_Snew, (unsigned)st_d0 * stk.rstr * 4u + st_vcol, nw);
         if (st_d0 == 0) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) xtop[(4 * st_bq + j) * PMG_XTP + st_w] = nw[j];
@@ -558,9 +578,14 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     __syncthreads();  // B2: stack top + token visible; every read of h_lds[0] (old) is done
 
     PMG_TICK(4)
-    if (decode && (misc[16] & misc[17] & misc[18] & misc[19] & misc[20] & misc[21] & misc[22] & misc[23])) {
+    bool all_done = decode;
+    if (decode) {
+#pragma unroll
+      for (int wv = 0; wv < WV; ++wv) all_done = all_done && (misc[16 + wv] != 0);
+    }
+    if (all_done) {
       // every row of this group has emitted stop_tok: fill the tail and leave
-      for (int idx = tid; idx < 16 * (N - i); idx += PMG_THREADS) {
+      for (int idx = tid; idx < 16 * (N - i); idx += NTHR) {
         const int bb = idx / (N - i), t = i + (idx - bb * (N - i));
         if (row0 + bb < B) a.tok_out[(size_t)(row0 + bb) * N + t] = a.stop_tok;
       }
@@ -653,7 +678,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
   // ---------------------------------------------------------------- epilogue
   if (decode && (lane & 31) == 0 && row0 + cs_bb < B) a.len_out[row0 + cs_bb] = mylen;
   if (a.h_out != nullptr) {
-    for (int idx = tid; idx < L * 16 * H; idx += PMG_THREADS) {
+    for (int idx = tid; idx < L * 16 * H; idx += NTHR) {
       const int l = idx / (16 * H);
       const int rem = idx - l * 16 * H;
       const int bb = rem / H, k = rem - bb * H;
@@ -664,7 +689,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_fwd_kernel(const FwdArgs a
     // step mode ran exactly one update: the new stack is in slot 1 (written by this workgroup)
     __syncthreads();
     const float* S1 = a.SB + ((size_t)1 * G + g) * a.SW;
-    for (int idx = tid; idx < D * W * 16; idx += PMG_THREADS) {
+    for (int idx = tid; idx < D * W * 16; idx += NTHR) {
       const int bb = idx & 15;
       const int dw = idx >> 4;
       if (row0 + bb < B) a.stack_out[(size_t)(row0 + bb) * D * W + dw] = S1[idx];
@@ -680,37 +705,49 @@ size_t pmg_fwd_lds_bytes(const FwdArgs* a) {
   return fl * sizeof(float);
 }
 
-template <int UPW, int TPP, int MODE, bool MULTI>
+template <int WV, int UPW, int TPP, int MODE, bool MULTI>
 static hipError_t launch_fwd_t(const FwdArgs* a, hipStream_t st) {
   const size_t lds = pmg_fwd_lds_bytes(a);
-  auto kern = pmg_fwd_kernel<UPW, TPP, MODE, MULTI>;
+  auto kern = pmg_fwd_kernel<WV, UPW, TPP, MODE, MULTI>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(a->G), dim3(PMG_THREADS), lds, st, *a);
+  hipLaunchKernelGGL(kern, dim3(a->G), dim3(WV * 64), lds, st, *a);
   return hipGetLastError();
 }
 
-template <int UPW, int TPP>
+template <int WV, int UPW, int TPP>
 static hipError_t launch_fwd_h(const FwdArgs* a, hipStream_t st) {
   const bool m = a->L > 1;
   switch (a->mode) {
     case PMG_FWD_DECODE:
-      return m ? launch_fwd_t<UPW, TPP, PMG_FWD_DECODE, true>(a, st) : launch_fwd_t<UPW, TPP, PMG_FWD_DECODE, false>(a, st);
+      return m ? launch_fwd_t<WV, UPW, TPP, PMG_FWD_DECODE, true>(a, st) : launch_fwd_t<WV, UPW, TPP, PMG_FWD_DECODE, false>(a, st);
     case PMG_FWD_TEACHER:
-      return m ? launch_fwd_t<UPW, TPP, PMG_FWD_TEACHER, true>(a, st) : launch_fwd_t<UPW, TPP, PMG_FWD_TEACHER, false>(a, st);
+      return m ? launch_fwd_t<WV, UPW, TPP, PMG_FWD_TEACHER, true>(a, st) : launch_fwd_t<WV, UPW, TPP, PMG_FWD_TEACHER, false>(a, st);
     case PMG_FWD_STEP:
-      return m ? launch_fwd_t<UPW, TPP, PMG_FWD_STEP, true>(a, st) : launch_fwd_t<UPW, TPP, PMG_FWD_STEP, false>(a, st);
+      return m ? launch_fwd_t<WV, UPW, TPP, PMG_FWD_STEP, true>(a, st) : launch_fwd_t<WV, UPW, TPP, PMG_FWD_STEP, false>(a, st);
   }
   return hipErrorInvalidValue;
 }
 
+// PMG_FWD_WV512: waves per workgroup of the H=512 variant (tuning knob: 8 or 16)
+#ifndef PMG_FWD_WV512
+#define PMG_FWD_WV512 8
+#endif
+#ifndef PMG_FWD_TPP16
+#define PMG_FWD_TPP16 1
+#endif
+
 hipError_t pmg_launch_fwd(const FwdArgs* a, hipStream_t st) {
   switch (a->H) {
-    case 128: return launch_fwd_h<1, 1>(a, st);
-    case 256: return launch_fwd_h<2, 2>(a, st);
-    case 512: return launch_fwd_h<4, 2>(a, st);
-    case 1024: return launch_fwd_h<8, 2>(a, st);
+    case 128: return launch_fwd_h<8, 1, 1>(a, st);
+    case 256: return launch_fwd_h<8, 2, 2>(a, st);
+#if PMG_FWD_WV512 == 16
+    case 512: return launch_fwd_h<16, 2, PMG_FWD_TPP16>(a, st);
+#else
+    case 512: return launch_fwd_h<8, 4, 2>(a, st);
+#endif
+    case 1024: return launch_fwd_h<8, 8, 2>(a, st);
   }
   return hipErrorInvalidValue;
 }
