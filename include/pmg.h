@@ -150,6 +150,23 @@ int pmg_step(const pmg_shape* s, const pmg_weights* w, const int64_t* tok,
              const float* hidden_in, const float* stack_in, float* hidden_out,
              float* stack_out, float* logits_out, void* ws, pmg_stream stream);
 
+/* Batched detokenisation -- replaces the per-molecule host loop
+ * `smiles_language.token_indexes_to_smiles(mol_num.tolist())` of reinforce.py:172-176 for
+ * the whole batch pmg_decode produced: row b of the result is the
+ * concatenation of the table strings of tokens[b, 0..len[b]), packed back to back.
+ *   tokens    [B, ld_tokens] int64 (tokens_out of pmg_decode, ld_tokens = gen_len)
+ *   len       [B] int32 (len_out of pmg_decode), clamped to [0, max_len]
+ *   tab_off   [V+1] int32, tab_bytes: token i is tab_bytes[tab_off[i] .. tab_off[i+1]) (UTF-8);
+ *             ids outside [0,V) and empty entries add nothing (index_to_token.get(i, ''))
+ *   max_tok_bytes  longest table string; longer entries are truncated to it
+ *   out_off   [B+1] int64: row b is out_bytes[out_off[b] .. out_off[b+1]); out_off[B] = total
+ *   out_bytes [out_cap] uint8, out_cap >= B * max_len * max_tok_bytes (checked on the host,
+ *             so no device-side overflow is possible and no synchronisation is needed)
+ * No workspace. */
+int pmg_detokenize(const int64_t* tokens, int64_t ld_tokens, const int32_t* len, int B, int max_len,
+                   const int32_t* tab_off, const uint8_t* tab_bytes, int V, int max_tok_bytes,
+                   int64_t* out_off, uint8_t* out_bytes, size_t out_cap, pmg_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,7 +54,7 @@ class PmgGrads(C.Structure):
 
 EXPORTS = (
     'pmg_abi_version', 'pmg_strerror', 'pmg_check_shape', 'pmg_workspace_bytes',
-    'pmg_decode', 'pmg_logprob_fwd', 'pmg_reinforce_bwd', 'pmg_step',
+    'pmg_decode', 'pmg_logprob_fwd', 'pmg_reinforce_bwd', 'pmg_step', 'pmg_detokenize',
 )
 
 
@@ -84,6 +84,9 @@ def _load():
     lib.pmg_step.argtypes = [
         C.POINTER(PmgShape), C.POINTER(PmgWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.pmg_detokenize.argtypes = [
+        C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     for name in EXPORTS[2:]:
         getattr(lib, name).restype = C.c_int
     if lib.pmg_abi_version() != PMG_ABI_VERSION:

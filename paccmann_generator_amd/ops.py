@@ -204,3 +204,73 @@ def teacher_forced_logprobs(weights: DecoderWeights, tokens: torch.Tensor, h0: t
     reward = torch.zeros(B, dtype=torch.float32, device=h0.device)
     _, logp = ReinforceLossFn.apply(tokens, h0, reward, 1.0, weights.dims, *[p.detach() for p in weights.flat()])
     return logp
+
+
+class TokenTable:
+    """index -> token string table of a SMILES/SELFIES language, resident on the device in the
+    layout pmg_detokenize reads (tab_off [V+1] int32, tab_bytes uint8, UTF-8).
+
+    ``index_to_token``: dict {int: str} (pytoda's ``SMILESLanguage.index_to_token``) or a list.
+    ``drop``: indexes whose text is dropped (e.g. pad/start/stop), like entries missing from the dict."""
+
+    def __init__(self, index_to_token, device, drop=()):
+        items = dict(enumerate(index_to_token)) if isinstance(index_to_token, (list, tuple)) \
+            else {int(k): v for k, v in dict(index_to_token).items()}
+        drop = set(int(i) for i in drop)
+        self.V = (max(items) + 1) if items else 1
+        enc = [b'' if (i in drop or i not in items) else str(items[i]).encode('utf-8') for i in range(self.V)]
+        off = [0]
+        for e in enc:
+            off.append(off[-1] + len(e))
+        self.max_tok_bytes = max(1, max((len(e) for e in enc), default=1))
+        self.ascii = all(e.isascii() for e in enc)
+        blob = b''.join(enc) or b'\0'
+        self.tab_off = torch.tensor(off, dtype=torch.int32, device=device)
+        self.tab_bytes = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+        self.device = torch.device(device)
+        self._out: Dict[tuple, tuple] = {}
+
+    def buffers(self, B: int, max_len: int):
+        cap = B * max_len * self.max_tok_bytes
+        key = (B, max_len)
+        buf = self._out.get(key)
+        if buf is None:
+            self._out.clear()
+            buf = (torch.empty(B + 1, dtype=torch.int64, device=self.device),
+                   torch.empty(cap, dtype=torch.uint8, device=self.device))
+            self._out[key] = buf
+        return buf
+
+
+@torch.no_grad()
+def detokenize_device(table: TokenTable, tokens: torch.Tensor, lens: torch.Tensor):
+    """Stream-ordered, no synchronisation: (out_off [B+1] int64, out_bytes uint8) on the device;
+    row b is out_bytes[out_off[b]:out_off[b+1]].  The buffers belong to ``table`` and are reused by
+    the next call with the same (B, max_len)."""
+    if tokens.dtype != torch.int64 or lens.dtype != torch.int32:
+        raise _ffi.PmgError('pmg_detokenize: tokens must be int64 and lens int32')
+    tokens = tokens.contiguous()
+    lens = lens.contiguous()
+    B, N = tokens.shape
+    if lens.numel() != B:
+        raise _ffi.PmgError('pmg_detokenize: one length per row required')
+    out_off, out_bytes = table.buffers(B, N)
+    rc = _ffi.lib.pmg_detokenize(_ffi._ptr(tokens), N, _ffi._ptr(lens), B, N, _ffi._ptr(table.tab_off),
+                                 _ffi._ptr(table.tab_bytes), table.V, table.max_tok_bytes, _ffi._ptr(out_off),
+                                 _ffi._ptr(out_bytes), out_bytes.numel(), _ffi.current_stream())
+    _ffi.check(rc, 'pmg_detokenize')
+    return out_off, out_bytes
+
+
+def detokenize(table: TokenTable, tokens: torch.Tensor, lens: torch.Tensor) -> List[str]:
+    """Batched twin of ``[lang.token_indexes_to_smiles(row[:n].tolist()) for row, n in ...]``
+    (reinforce.py:172-176): one device pass, two device->host copies, B string slices."""
+    if tokens.shape[0] == 0:
+        return []
+    out_off, out_bytes = detokenize_device(table, tokens, lens)
+    off = out_off.cpu().tolist()
+    blob = out_bytes[:off[-1]].cpu().numpy().tobytes()
+    if table.ascii:
+        text = blob.decode('ascii')
+        return [text[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+    return [blob[off[i]:off[i + 1]].decode('utf-8') for i in range(len(off) - 1)]

@@ -39,10 +39,13 @@ def _rdkit_validity():
 class Reinforce(object):
 
     def __init__(self, generator, encoder, params, model_name, logger, is_valid: Optional[Callable] = None,
-                 reward_fn: Optional[Callable] = None, process_group=None, score_fn: Optional[Callable] = None):
+                 reward_fn: Optional[Callable] = None, process_group=None, score_fn: Optional[Callable] = None,
+                 is_valid_batch: Optional[Callable] = None):
         """Same positional arguments as reinforce.py:16.  Keyword-only extras:
 
         is_valid:      host validity check replacing Chem.MolFromSmiles (reinforce.py:195)
+        is_valid_batch: same over the whole list ``f(list[str]) -> list[bool]`` (lets the caller fan
+                       the RDKit work out over processes); takes precedence over is_valid
         reward_fn:     host reward ``f(smiles, target) -> array`` (reinforce_omics.py:209-222)
         score_fn:      host scoring used by generate_compounds_and_evaluate (defaults to reward_fn)
         process_group: torch.distributed group for data-parallel latent sharding
@@ -69,6 +72,7 @@ class Reinforce(object):
         self.model_path = os.path.join(params.get('model_folder', 'biased_models'), model_name)
         self.weights_path = os.path.join(self.model_path, 'weights/{}')
         self.is_valid = is_valid if is_valid is not None else _rdkit_validity()
+        self.is_valid_batch = is_valid_batch
         self.reward_fn = reward_fn
         self.score_fn = score_fn
         self.process_group = process_group
@@ -119,26 +123,51 @@ class Reinforce(object):
             search=SamplingSearch(temperature=self.temperature),
             seq_index_base=seq_index_base, early_exit=early_exit)
 
+    def _token_table(self, lang):
+        """Device table for pmg_detokenize when the language exposes ``index_to_token`` (pytoda's
+        SMILESLanguage does); None otherwise -> per-row ``token_indexes_to_smiles`` as the reference."""
+        itt = getattr(lang, 'index_to_token', None)
+        if itt is None:
+            return None
+        cached = getattr(self, '_tt_cache', None)
+        if cached is None or cached[0] is not itt or cached[1] != len(itt):
+            drop = getattr(lang, 'detokenize_drop', ())
+            cached = (itt, len(itt), ops.TokenTable(itt, self.device, drop=drop))
+            self._tt_cache = cached
+        return cached[2]
+
     def get_smiles_from_latent(self, latent, remove_invalid=True):
-        """reinforce.py:149-211.  Returns (smiles, nums, valid_idxs)."""
+        """reinforce.py:149-211.  Returns (smiles, nums, valid_idxs).
+
+        With a language that exposes ``index_to_token`` the whole batch is detokenised on the device
+        (ops.detokenize) and the ``+ 2 x stop`` rows (reinforce.py:177-184) are cut from one padded
+        matrix built on the device; otherwise the per-row host loop of the reference runs."""
         lang = self.generator.smiles_language
-        mols_numerical = self.generator.generate(
-            self._decoder_latent(latent),
-            prime_input=torch.Tensor([lang.start_index]).long(),
-            end_token=torch.Tensor([lang.stop_index]).long(),
-            generate_len=self.generate_len,
-            search=SamplingSearch(temperature=self.temperature),
-        )
-        stops = torch.tensor(2 * [lang.stop_index])
-        smiles_num_tuple = [
-            (lang.token_indexes_to_smiles(mol_num.tolist()), torch.cat([mol_num.long(), stops]))
-            for mol_num in iter(mols_numerical)
-        ]
-        numericals = [sm[1] for sm in smiles_num_tuple]
-        smiles = [lang.selfies_to_smiles(sm[0]) for sm in smiles_num_tuple]
-        if self.is_valid is None:
+        table = self._token_table(lang)
+        if table is not None:
+            tokens, lens = self.sample_tokens(latent)
+            strings = ops.detokenize(table, tokens, lens)
+            padded = pad_rows_on_device(tokens, lens, lang.stop_index, t_max=tokens.shape[1] + 2).t().cpu()
+            numericals = [padded[i, :n + 2] for i, n in enumerate(lens.cpu().tolist())]
+        else:
+            mols_numerical = self.generator.generate(
+                self._decoder_latent(latent),
+                prime_input=torch.Tensor([lang.start_index]).long(),
+                end_token=torch.Tensor([lang.stop_index]).long(),
+                generate_len=self.generate_len,
+                search=SamplingSearch(temperature=self.temperature),
+            )
+            stops = torch.tensor(2 * [lang.stop_index])
+            rows = list(iter(mols_numerical))
+            strings = [lang.token_indexes_to_smiles(r.tolist()) for r in rows]
+            numericals = [torch.cat([r.long(), stops]) for r in rows]
+        smiles = [lang.selfies_to_smiles(s) for s in strings]
+        if self.is_valid_batch is not None:
+            ok = [bool(v) for v in self.is_valid_batch(smiles)]
+        elif self.is_valid is not None:
+            ok = [bool(self.is_valid(s)) for s in smiles]
+        else:
             raise RuntimeError('no validity check available: pass is_valid= (RDKit is not importable)')
-        ok = [bool(self.is_valid(s)) for s in smiles]
         valid_idxs = [i for i in range(len(ok)) if ok[i]]
         keep = [i for i in range(len(ok)) if not (remove_invalid and not ok[i])]
         if self.logger is not None:

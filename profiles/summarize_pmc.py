@@ -36,7 +36,7 @@ def main():
     fwd = [k for k in data['write'] if 'pmg_fwd' in k]
     if len(fwd) > 1:
         for k in fwd:
-            mode = int(k.split('<')[1].split(',')[2])
+            mode = int(k.split('<')[1].split('>')[0].split(',')[-2])     # <..., MODE, MULTI>: second to last
             name = {0: 'decode', 1: 'teacher_fwd'}.get(mode)
             if name:
                 rows.append((name, f'pmg_fwd_kernel ({name})', len(data['fetch'][k]), med(data['fetch'][k]),
