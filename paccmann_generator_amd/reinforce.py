@@ -149,6 +149,7 @@ class Reinforce(object):
             strings = ops.detokenize(table, tokens, lens)
             padded = pad_rows_on_device(tokens, lens, lang.stop_index, t_max=tokens.shape[1] + 2).t().cpu()
             numericals = [padded[i, :n + 2] for i, n in enumerate(lens.cpu().tolist())]
+            self._last_sample = (tokens, lens, numericals)      # lets _policy_gradient pad on the device
         else:
             mols_numerical = self.generator.generate(
                 self._decoder_latent(latent),
@@ -221,13 +222,27 @@ class Reinforce(object):
                 self.logger.warning('no valid molecule in the batch: update skipped')
             return torch.tensor(0.0), 0.0
         rewards = self.get_reward(valid_smiles, target)
-        padded_nums = torch.nn.utils.rnn.pad_sequence(valid_nums)
+        padded_nums = self._padded_valid(valid_nums, valid_idx)
         lrps = 1
         if self.encoder is not None and \
                 self.generator.decoder.latent_dim == 2 * getattr(self.encoder, 'latent_size', -1):
             lrps = 2
         r, loss = self.learn(latent_z, padded_nums, valid_idx, rewards, lrps)
         return r, loss.item()
+
+    def _padded_valid(self, valid_nums, valid_idx):
+        """pad_sequence(valid_nums) (reinforce_omics.py:304).  When the rows are the ones the device
+        detokeniser path just produced, the same [T_max, B_valid] matrix is built on the device from
+        the decoded tokens instead of from B_valid host tensors."""
+        last = getattr(self, '_last_sample', None)
+        self._last_sample = None
+        if last is not None and len(valid_nums) == len(valid_idx) and len(valid_idx) > 0 and \
+                all(valid_nums[j] is last[2][i] for j, i in ((0, valid_idx[0]), (-1, valid_idx[-1]))):
+            tokens, lens, _ = last
+            idx = torch.as_tensor(valid_idx, dtype=torch.long, device=tokens.device)
+            return pad_rows_on_device(tokens.index_select(0, idx), lens.index_select(0, idx),
+                                      self.generator.smiles_language.stop_index)
+        return torch.nn.utils.rnn.pad_sequence(valid_nums)
 
     def get_reward(self, valid_smiles, target):
         if self.reward_fn is None:
