@@ -54,6 +54,19 @@ def test_train_parity_large_vocab(gpu):
     assert r['boundary'] <= 2
 
 
+@pytest.mark.parametrize('over', [
+    dict(stack_width=64, stack_depth=2),                       # widest stack the ABI admits, shallowest depth
+    dict(stack_width=1, stack_depth=3, embedding_size=1),      # one-column stack, one-column embedding
+    dict(vocab_size=5, embedding_size=5),                      # pad, unk, start, stop + one real token
+    dict(vocab_size=189, stack_width=64),                      # 3 + W + V = 256: the extras tile limit
+    dict(n_layers=4, rnn_cell_size=256, stack_depth=30),       # deepest GRU, stack deeper than the sequence
+], ids=['w64d2', 'w1e1', 'v5', 'v189w64', 'l4'])
+def test_parity_edge_shapes(gpu, over):
+    cfg = dict(P.TINY, **over)
+    P.check_train(cfg, B=19, T=7, tol=TOL)
+    assert P.check_greedy(cfg, 19, 9)['mismatched_rows'] == 0
+
+
 def test_train_parity_cfg1(gpu):
     P.check_train(P.CFG1, B=64, T=100, tol=TOL)
 
