@@ -36,7 +36,7 @@ def fwd():
 def bwd(flags):
     _ffi.check(_ffi.lib.pmg_reinforce_bwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(rewards), 1.0 / B, flags, C.byref(gstruct), _ffi._ptr(gh0), _ffi._ptr(loss), _ffi._ptr(ws), st), 'bwd')
 fwd(); bwd(_ffi.PMG_FLAG_SKIP_WGRAD); torch.cuda.synchronize()
-os.environ['PMG_DEBUG'] = '0x8000'
+os.environ['PMG_DEBUG'] = hex(0x8000 | int(os.environ.get('ABL', '0'), 16))
 for which in os.environ.get('WHICH', 'fwd,bwd').split(','):
     if which == 'fwd': fwd()
     else: bwd(_ffi.PMG_FLAG_SKIP_WGRAD)
