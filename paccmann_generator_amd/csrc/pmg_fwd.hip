@@ -116,45 +116,74 @@ struct StackSide {
 // Two register sets (wa, wb): the loads of group kg+1 are in flight while the MFMAs of group kg
 // run (the sched_barriers keep hipcc from re-fusing load and use, which it otherwise does).
 // KG is even; with an active side job KG is a multiple of 8 and the loop is unrolled by four.
+// `wa` is owned by the caller: with `loaded` it already holds group 0 of this pass, and on return it
+// holds group 0 of the weights at (nso, nts) -- the next pass or the next product -- so that no pass
+// starts by waiting for an L2 round trip with every wave of the workgroup stalled at once.
 template <int UPW, int TPP, class Side>
 __device__ __forceinline__ void gemm3_pass(f32x4 (&ar)[UPW], f32x4 (&az)[UPW], f32x4 (&at)[UPW], const int u0,
                                            const __amdgpu_buffer_rsrc_t rs, const unsigned voff,
-                                           const unsigned soff, const int KG, const float* xrow, Side& side) {
+                                           const unsigned soff, const int KG, const float* xrow, Side& side,
+                                           float4 (&wa)[3 * TPP], const bool loaded, const unsigned nso,
+                                           const unsigned nts) {
   constexpr int NT = 3 * TPP;
   const unsigned ts = (unsigned)KG * 1024u;  // bytes per tile
-  float4 wa[NT], wb[NT];
-#define PMG_LOAD(dst, kgi) \
+  float4 wb[NT];
+#define PMG_LOAD0(dst, kgi) \
   _Pragma("unroll") for (int t = 0; t < NT; ++t) dst[t] = pmg_bload(rs, voff, soff + t * ts + (unsigned)(kgi) * 1024u);
+#ifdef PMG_ABL_NOLOAD  /* timing experiment: weights loaded once per pass */
+#define PMG_LOAD(dst, kgi) asm volatile("" : "+v"(dst[0].x));
+#else
+#define PMG_LOAD(dst, kgi) PMG_LOAD0(dst, kgi)
+#endif
+#define PMG_LOADX(dst, so, tsx) \
+  _Pragma("unroll") for (int t = 0; t < NT; ++t) dst[t] = pmg_bload(rs, voff, (so) + t * (tsx));
+#ifdef PMG_ABL_NOMFMA  /* timing experiment: one VALU fma in place of each MFMA */
+#define PMG_STEP(wc, C)                                                                          \
+  _Pragma("unroll") for (int uu = 0; uu < TPP; ++uu) {                                           \
+    ar[u0 + uu].x += wc[3 * uu + 0].C * x.C;                                                     \
+    az[u0 + uu].x += wc[3 * uu + 1].C * x.C;                                                     \
+    at[u0 + uu].x += wc[3 * uu + 2].C * x.C;                                                     \
+  }
+#else
 #define PMG_STEP(wc, C)                                                                          \
   _Pragma("unroll") for (int uu = 0; uu < TPP; ++uu) {                                           \
     ar[u0 + uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[3 * uu + 0].C, x.C, ar[u0 + uu], 0, 0, 0); \
     az[u0 + uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[3 * uu + 1].C, x.C, az[u0 + uu], 0, 0, 0); \
     at[u0 + uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[3 * uu + 2].C, x.C, at[u0 + uu], 0, 0, 0); \
   }
+#endif
 #define PMG_DGROUP(U, kgq)                                                                       \
   {                                                                                              \
     const int kg_ = (kgq);                                                                       \
     PMG_LOAD(wb, kg_ + 1)                                                                        \
+    const float4 xb = *reinterpret_cast<const float4*>(xrow + 16 * kg_ + 16);                    \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     side.template step<U>();                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     {                                                                                            \
-      const float4 x = *reinterpret_cast<const float4*>(xrow + 16 * kg_);                        \
+      const float4 x = xa;                                                                       \
       PMG_STEP(wa, x) PMG_STEP(wa, y) PMG_STEP(wa, z) PMG_STEP(wa, w)                            \
     }                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     {                                                                                            \
-      const int kn = (kg_ + 2 < KG) ? kg_ + 2 : kg_;                                             \
-      PMG_LOAD(wa, kn)                                                                           \
+      const bool more_ = kg_ + 2 < KG;                                                           \
+      const unsigned so_ = more_ ? soff + (unsigned)(kg_ + 2) * 1024u : nso;                     \
+      const unsigned ts_ = more_ ? ts : nts;                                                     \
+      PMG_LOADX(wa, so_, ts_)                                                                    \
+      xa = *reinterpret_cast<const float4*>(xrow + 16 * (more_ ? kg_ + 2 : kg_));                \
     }                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     {                                                                                            \
-      const float4 x = *reinterpret_cast<const float4*>(xrow + 16 * kg_ + 16);                   \
+      const float4 x = xb;                                                                       \
       PMG_STEP(wb, x) PMG_STEP(wb, y) PMG_STEP(wb, z) PMG_STEP(wb, w)                            \
     }                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                           \
   }
-  PMG_LOAD(wa, 0)
+  if (!loaded) PMG_LOAD0(wa, 0)
+  float4 xa = *reinterpret_cast<const float4*>(xrow);  // B operand, one half group ahead of its MFMAs
+#ifdef PMG_ABL_NOLOAD
+  PMG_LOAD0(wb, 1)
+#endif
   if constexpr (Side::kActive) {
 #pragma unroll 1
     for (int kg = 0; kg < KG; kg += 8) {
@@ -167,18 +196,41 @@ __device__ __forceinline__ void gemm3_pass(f32x4 (&ar)[UPW], f32x4 (&az)[UPW], f
 #undef PMG_DGROUP
 #undef PMG_STEP
 #undef PMG_LOAD
+#undef PMG_LOAD0
+#undef PMG_LOADX
 }
 
+// byte offset of (first tile of this wave, group 0) of a gate product with KG groups
+template <int UPW>
+__device__ __forceinline__ unsigned gemm3_first(const unsigned obase, const int wave, const int KG) {
+  return obase + (unsigned)(3 * wave * UPW) * (unsigned)KG * 1024u;
+}
+// prefetch of group 0 of a product's first pass into the caller's register set
+template <int NT>
+__device__ __forceinline__ void gemm3_preload(float4 (&wa)[NT], const __amdgpu_buffer_rsrc_t rs, const unsigned voff,
+                                              const unsigned so, const unsigned ts) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wa[t] = pmg_bload(rs, voff, so + t * ts);
+}
+
+// nso/nts: where the product that runs next starts (gemm3_first of it, its tile stride); the last
+// pass leaves that group in `wa`.  nso = this product's own first group when there is nothing to
+// prefetch (a harmless re-read).
 template <int UPW, int TPP, class Side>
 __device__ __forceinline__ void gemm3(f32x4 (&ar)[UPW], f32x4 (&az)[UPW], f32x4 (&at)[UPW],
                                       const __amdgpu_buffer_rsrc_t rs, const unsigned voff, const unsigned obase,
-                                      const int KG, const float* xrow, const int wave, Side& side) {
+                                      const int KG, const float* xrow, const int wave, Side& side,
+                                      float4 (&wa)[3 * TPP], const bool loaded, const unsigned nso,
+                                      const unsigned nts) {
   // this wave's tiles: 3*(wave*UPW + u), u in [0,UPW)
+  const unsigned ts = (unsigned)KG * 1024u;
 #pragma unroll
   for (int ps = 0; ps < UPW / TPP; ++ps) {
     const int u0 = ps * TPP;
-    const unsigned soff = obase + (unsigned)(3 * (wave * UPW + u0)) * (unsigned)KG * 1024u;
-    gemm3_pass<UPW, TPP>(ar, az, at, u0, rs, voff, soff, KG, xrow, side);
+    const unsigned soff = obase + (unsigned)(3 * (wave * UPW + u0)) * ts;
+    const bool last = ps == UPW / TPP - 1;
+    gemm3_pass<UPW, TPP>(ar, az, at, u0, rs, voff, soff, KG, xrow, side, wa, loaded || ps > 0,
+                         last ? nso : soff + (unsigned)(3 * TPP) * ts, last ? nts : ts);
   }
 }
 
@@ -344,6 +396,8 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
   }
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   NoSide no_side;
+  float4 wpre[3 * TPP];        // weight group prefetched for the product that runs next (see gemm3)
+  const bool wpre_ok = false;  // the layer-0 W_hh product loads its own first group
   const __amdgpu_buffer_rsrc_t bgr0 = pmg_rsrc(a.BG[0], (unsigned)H * 16u);
   const __amdgpu_buffer_rsrc_t gtr = pmg_rsrc(a.GTAB, (unsigned)V * 3u * (unsigned)H * 4u);
   const unsigned vq = 4u * q * 4u;                       // feature 4q of a 16-feature tile
@@ -570,7 +624,10 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
       az[u] = bl4(bgr0, vq, so + gH);
       ah[u] = bl4(bgr0, vq, so + 3u * gH);
     }
-    if (!(dbg & 0x400)) gemm3<UPW, TPP>(ar, az, ah, wrs, voff, a.oWHH[0], KGH, h_lds + (size_t)b * HP + 4 * q, wave, stk);
+    // the last pass leaves group 0 of the stack-top product in wpre (consumed after barrier B2)
+    if (!(dbg & 0x400))
+      gemm3<UPW, TPP>(ar, az, ah, wrs, voff, a.oWHH[0], KGH, h_lds + (size_t)b * HP + 4 * q, wave, stk, wpre, wpre_ok,
+                      gemm3_first<UPW>(a.oWIH[0], wave, PMG_KS / 16), (unsigned)(PMG_KS / 16) * 1024u);
     while (stk.sj < st_dch) {  // rows the GEMM loop did not reach (four calls keep the ring slots aligned)
       stk.template step<0>(); stk.template step<1>(); stk.template step<2>(); stk.template step<3>();
     }
@@ -595,7 +652,9 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
     // ------------------------------------------------------------ layer 0: stack-top GEMM, table, gates
 #pragma unroll
     for (int u = 0; u < UPW; ++u) ai[u] = bl4(bgr0, vq, (unsigned)(16 * (wave * UPW + u) + 2 * H) * 4u);
-    if (!(dbg & 0x800)) gemm3<UPW, TPP>(ar, az, ai, wrs, voff, a.oWIH[0], PMG_KS / 16, xtop + b * PMG_XTP + 4 * q, wave, no_side);
+    if (!(dbg & 0x800))
+      gemm3<UPW, TPP>(ar, az, ai, wrs, voff, a.oWIH[0], PMG_KS / 16, xtop + b * PMG_XTP + 4 * q, wave, no_side, wpre,
+                      !(dbg & 0x400), gemm3_first<UPW>(a.oWIH[0], wave, PMG_KS / 16), (unsigned)(PMG_KS / 16) * 1024u);
     {
       const unsigned vtok = ((unsigned)misc[b] * 3u * (unsigned)H + 4u * q) * 4u;  // this row's table line
 #pragma unroll
@@ -640,8 +699,10 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
         ai[u] = ld4(a.BG[l] + 2 * H + j0);
         ah[u] = ld4(a.BG[l] + 3 * H + j0);
       }
-      gemm3<UPW, TPP>(ar, az, ah, wrs, voff, a.oWHH[l], KGH, h_lds + (size_t)(l * 16 + b) * HP + 4 * q, wave, no_side);
-      gemm3<UPW, TPP>(ar, az, ai, wrs, voff, a.oWIH[l], KGH, h_lds + (size_t)((l - 1) * 16 + b) * HP + 4 * q, wave, no_side);
+      gemm3<UPW, TPP>(ar, az, ah, wrs, voff, a.oWHH[l], KGH, h_lds + (size_t)(l * 16 + b) * HP + 4 * q, wave, no_side,
+                      wpre, false, gemm3_first<UPW>(a.oWIH[l], wave, KGH), (unsigned)KGH * 1024u);
+      gemm3<UPW, TPP>(ar, az, ai, wrs, voff, a.oWIH[l], KGH, h_lds + (size_t)((l - 1) * 16 + b) * HP + 4 * q, wave, no_side,
+                      wpre, true, gemm3_first<UPW>(a.oWIH[l], wave, KGH), (unsigned)KGH * 1024u);
       __syncthreads();  // every read of h_lds[l] (old) is done
 #pragma unroll
       for (int u = 0; u < UPW; ++u) {
