@@ -406,7 +406,7 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
 #ifdef PMG_PROFILE
   // -DPMG_PROFILE build + PMG_DEBUG bit 0x8000: per-phase cycle counters of workgroup 0, printed at the end
   const bool prof = (dbg & 0x8000) != 0;
-  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #define PMG_TICK(k) if (prof) { const long long tn_ = (long long)__builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; }
 #else
@@ -617,6 +617,7 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
       hhh0 = pmg_rsrc(a.HH[0] + (((size_t)(i + 1) * G + g) * H) * 16, (unsigned)H * 64u);
     }
     // ------------------------------------------------------------ layer 0: gh GEMM
+    PMG_TICK(7)
 #pragma unroll
     for (int u = 0; u < UPW; ++u) {
       const unsigned so = (unsigned)(16 * (wave * UPW + u)) * 4u, gH = (unsigned)H * 4u;
@@ -628,6 +629,7 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
     if (!(dbg & 0x400))
       gemm3<UPW, TPP>(ar, az, ah, wrs, voff, a.oWHH[0], KGH, h_lds + (size_t)b * HP + 4 * q, wave, stk, wpre, wpre_ok,
                       gemm3_first<UPW>(a.oWIH[0], wave, PMG_KS / 16), (unsigned)(PMG_KS / 16) * 1024u);
+    PMG_TICK(8)
     while (stk.sj < st_dch) {  // rows the GEMM loop did not reach (four calls keep the ring slots aligned)
       stk.template step<0>(); stk.template step<1>(); stk.template step<2>(); stk.template step<3>();
     }
@@ -733,8 +735,8 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
 
 #ifdef PMG_PROFILE
   if (prof && g == 0 && lane == 0)
-    printf("fwd wave %d cycles: extras %lld syncB1 %lld logits %lld gh+stack %lld syncB2 %lld top+gates %lld syncB3 %lld\n", wave,
-           tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6]);
+    printf("fwd wave %d cycles: extras %lld syncB1 %lld logits %lld stackprep %lld gh %lld tail %lld syncB2 %lld top+gates %lld syncB3 %lld\n", wave,
+           tph[0], tph[1], tph[2], tph[7], tph[8], tph[3], tph[4], tph[5], tph[6]);
 #endif
   // ---------------------------------------------------------------- epilogue
   if (decode && (lane & 31) == 0 && row0 + cs_bb < B) a.len_out[row0 + cs_bb] = mylen;
