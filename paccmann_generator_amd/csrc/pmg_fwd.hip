@@ -618,13 +618,10 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
     }
     // ------------------------------------------------------------ layer 0: gh GEMM
     PMG_TICK(7)
+    // layer 0 starts every accumulator at zero: b_ih and b_hh{r,z} live in the token table, b_hn
+    // (BG[0][3]) is added with the gates, so no product waits for a bias load
 #pragma unroll
-    for (int u = 0; u < UPW; ++u) {
-      const unsigned so = (unsigned)(16 * (wave * UPW + u)) * 4u, gH = (unsigned)H * 4u;
-      ar[u] = bl4(bgr0, vq, so);
-      az[u] = bl4(bgr0, vq, so + gH);
-      ah[u] = bl4(bgr0, vq, so + 3u * gH);
-    }
+    for (int u = 0; u < UPW; ++u) ar[u] = az[u] = ah[u] = zero4;
     // the last pass leaves group 0 of the stack-top product in wpre (consumed after barrier B2)
     if (!(dbg & 0x400))
       gemm3<UPW, TPP>(ar, az, ah, wrs, voff, a.oWHH[0], KGH, h_lds + (size_t)b * HP + 4 * q, wave, stk, wpre, wpre_ok,
@@ -652,8 +649,12 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
     }
 
     // ------------------------------------------------------------ layer 0: stack-top GEMM, table, gates
+    f32x4 bhn[UPW];
 #pragma unroll
-    for (int u = 0; u < UPW; ++u) ai[u] = bl4(bgr0, vq, (unsigned)(16 * (wave * UPW + u) + 2 * H) * 4u);
+    for (int u = 0; u < UPW; ++u) {
+      ai[u] = zero4;
+      bhn[u] = bl4(bgr0, vq, (unsigned)(16 * (wave * UPW + u) + 3 * H) * 4u);
+    }
     if (!(dbg & 0x800))
       gemm3<UPW, TPP>(ar, az, ai, wrs, voff, a.oWIH[0], PMG_KS / 16, xtop + b * PMG_XTP + 4 * q, wave, no_side, wpre,
                       !(dbg & 0x400), gemm3_first<UPW>(a.oWIH[0], wave, PMG_KS / 16), (unsigned)(PMG_KS / 16) * 1024u);
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
         const f32x4 vr = ar[u] + bl4(gtr, vtok, so);
         const f32x4 vz = az[u] + bl4(gtr, vtok, so + gH);
         const f32x4 vi = ai[u] + bl4(gtr, vtok, so + 2u * gH);
-        const f32x4 vh = ah[u];
+        const f32x4 vh = ah[u] + bhn[u];
         f32x4 r, z, n, hn;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
