@@ -41,6 +41,42 @@ __global__ __launch_bounds__(512, 2) void k(const float* w, float* out, long lon
       float4 xa = LDSX ? *reinterpret_cast<const float4*>(xrow) : make_float4(1.f, 1.f, 1.f, 1.f);
 #pragma unroll 1
       for (int kg = 0; kg < KG; kg += 2) {
+        if (DEPTH == 4) {
+          // wb(kg+1) loads ride in the shadow of the first MFMAs of the wa block, wa(kg+2) loads in
+          // the shadow of the first MFMAs of the wb block: one VMEM issue per MFMA issue
+          const int kn = kg + 2 < KG ? kg + 2 : kg;
+          float4 xb = *reinterpret_cast<const float4*>(xrow + 16 * kg + 16);
+          float4 wn[NT];
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            const float4 x = xa;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t].x, x.x, acc[t], 0, 0, 0);
+              wb[t] = bload(rs, voff, soff + (kg + 1) * 1024u + t * ts);
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            STEP(wa, y) STEP(wa, z) STEP(wa, w)
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          xa = *reinterpret_cast<const float4*>(xrow + 16 * kn);
+          {
+            const float4 x = xb;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[t].x, x.x, acc[t], 0, 0, 0);
+              wn[t] = bload(rs, voff, soff + kn * 1024u + t * ts);
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            STEP(wb, y) STEP(wb, z) STEP(wb, w)
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) wa[t] = wn[t];
+          continue;
+        }
         LOAD(wb, soff + (kg + 1) * 1024u)
         float4 xb = xa;
         if (LDSX) xb = *reinterpret_cast<const float4*>(xrow + 16 * kg + 16);
@@ -92,5 +128,6 @@ int main() {
   run<true, true, true>("+ both + barrier per step", w, S);
   run<false, false, true>("mfma only + barrier", w, S);
   run<true, true, true, 3>("+ both + barrier, preload", w, S);
+  run<true, true, true, 4>("+ both + barrier, interleaved", w, S);
   return 0;
 }
