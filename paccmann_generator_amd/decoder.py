@@ -146,8 +146,15 @@ class Generator(nn.Module):
         torch.save(self.state_dict(), path, *args, **kwargs)
 
     def load(self, path, *args, **kwargs):
+        """Plain ``state_dict`` checkpoint, as TeacherVAE.save writes it (keys ``encoder.*`` and
+        ``decoder.*``).  When this generator was built without the SMILES encoder (the REINFORCE loop
+        never calls it) the ``encoder.*`` entries of the file are skipped; every ``decoder.*`` entry
+        must still match."""
         kwargs.setdefault('weights_only', True)
-        self.load_state_dict(torch.load(path, *args, **kwargs))
+        state = torch.load(path, *args, **kwargs)
+        if self.encoder is None:
+            state = {k: v for k, v in state.items() if not k.startswith('encoder.')}
+        self.load_state_dict(state)
 
     load_model = load
 
