@@ -77,12 +77,15 @@ __global__ __launch_bounds__(512, 2) void k(const float* w, float* out, long lon
           for (int t = 0; t < NT; ++t) wa[t] = wn[t];
           continue;
         }
+        if (DEPTH == 5) __builtin_amdgcn_s_setprio(0);
         LOAD(wb, soff + (kg + 1) * 1024u)
         float4 xb = xa;
         if (LDSX) xb = *reinterpret_cast<const float4*>(xrow + 16 * kg + 16);
         __builtin_amdgcn_sched_barrier(0);
+        if (DEPTH == 5) __builtin_amdgcn_s_setprio(2);
         { const float4 x = xa; STEP(wa, x) STEP(wa, y) STEP(wa, z) STEP(wa, w) }
         __builtin_amdgcn_sched_barrier(0);
+        if (DEPTH == 5) __builtin_amdgcn_s_setprio(0);
         {
           const int kn = kg + 2 < KG ? kg + 2 : kg;
           const unsigned so = (DEPTH == 3 && kg + 2 >= KG) ? nsoff : soff + kn * 1024u;
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(512, 2) void k(const float* w, float* out, long lon
           if (LDSX) xa = *reinterpret_cast<const float4*>(xrow + 16 * kn);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (DEPTH == 5) __builtin_amdgcn_s_setprio(2);
         { const float4 x = xb; STEP(wb, x) STEP(wb, y) STEP(wb, z) STEP(wb, w) }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -129,5 +133,6 @@ int main() {
   run<false, false, true>("mfma only + barrier", w, S);
   run<true, true, true, 3>("+ both + barrier, preload", w, S);
   run<true, true, true, 4>("+ both + barrier, interleaved", w, S);
+  run<true, true, true, 5>("+ both + barrier, mfma prio", w, S);
   return 0;
 }
