@@ -127,6 +127,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
   float lossacc = 0.0f;  // threads 0..15: sum_p R_b * logp[p][b]
   float myR = 0.0f;
   if (tid < 16) myR = (row0 + tid < B) ? a.reward[row0 + tid] : 0.0f;
+  const float rowR = (row0 + (tid & 15) < B) ? a.reward[row0 + (tid & 15)] : 0.0f;  // reward of row tid&15
   __syncthreads();
 
   constexpr int NCB = UPW < 4 ? UPW : 4;  // chunk buffers (and chunks per round)
@@ -143,6 +144,21 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
   // p == N is the virtual step that only injects dlogits_{N-1}
   for (int p = N; p >= 0; --p) {
     const bool virt = (p == N);
+    // dlogits_{p-1} inputs (probabilities, target token; nothing recurrent) are requested here, one
+    // step's worth of products before they are used, so their latency is off the serial chain.
+    // Thread tid covers row tid&15 and vocabulary entries tid>>4 and 32 + (tid>>4); larger
+    // vocabularies load the rest in place.
+    const int dl_row = row0 + (tid & 15);
+    int dl_y = 0;
+    float dl_pr[2] = {0.0f, 0.0f};
+    if (p >= 1) {
+      dl_y = (dl_row < B) ? (int)a.tokens[(size_t)p * B + dl_row] : 0;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int v = (tid >> 4) + 32 * k;
+        if (v < V) dl_pr[k] = pmg_ld1h<4>(a.PR + (((size_t)(p - 1) * G + g) * a.VP + v) * 16 + (tid & 15));
+      }
+    }
     if (!virt) {
       f32x4 dxa[UPW];
 #pragma unroll
@@ -348,15 +364,18 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
     // ------------------------------------------------------------ dlogits_{p-1}, loss
     {
       const float sc = a.scale;
-      for (int idx = tid; idx < 16 * V; idx += PMG_THREADS) {
-        const int bb = idx & 15, v = idx >> 4;
+      const int bb = tid & 15;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int v = (tid >> 4) + 32 * k;
+        if (v < V) dxl[bb * XP + 3 + W + v] = (p >= 1) ? sc * rowR * (dl_pr[k] - ((v == dl_y) ? 1.0f : 0.0f)) : 0.0f;
+      }
+      for (int idx = tid + 2 * PMG_THREADS; idx < 16 * V; idx += PMG_THREADS) {  // V > 64
+        const int v = idx >> 4;
         float val = 0.0f;
         if (p >= 1) {
-          const int row = row0 + bb;
-          const float R = (row < B) ? a.reward[row] : 0.0f;
-          const int y = (row < B) ? (int)a.tokens[(size_t)p * B + row] : 0;
           const float pr = pmg_ld1h<4>(a.PR + (((size_t)(p - 1) * G + g) * a.VP + v) * 16 + bb);
-          val = sc * R * (pr - ((v == y) ? 1.0f : 0.0f));
+          val = sc * rowR * (pr - ((v == dl_y) ? 1.0f : 0.0f));
         }
         dxl[bb * XP + 3 + W + v] = val;
       }
