@@ -159,6 +159,11 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
         if (v < V) dl_pr[k] = pmg_ld1h<4>(a.PR + (((size_t)(p - 1) * G + g) * a.VP + v) * 16 + (tid & 15));
       }
     }
+    float ct_a[3] = {0.0f, 0.0f, 0.0f};  // stack controls of row tid (threads 0..15), same early request
+    if (!virt && tid < 16) {
+      const float* ct = a.CT + ((size_t)p * G + g) * 64;
+      ct_a[0] = ct[tid]; ct_a[1] = ct[16 + tid]; ct_a[2] = ct[32 + tid];
+    }
     if (!virt) {
       f32x4 dxa[UPW];
 #pragma unroll
@@ -389,8 +394,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
         const float* rp = red + (wv * 4 + bq) * 12;
         dpu += rp[j]; dpo += rp[4 + j]; dno += rp[8 + j];
       }
-      const float* ct = a.CT + ((size_t)p * G + g) * 64;
-      const float a0 = ct[tid], a1 = ct[16 + tid], a2 = ct[32 + tid];
+      const float a0 = ct_a[0], a1 = ct_a[1], a2 = ct_a[2];
       const float s = a0 * dpu + a1 * dpo + a2 * dno;
       dxl[tid * XP + 0] = a0 * (dpu - s);
       dxl[tid * XP + 1] = a1 * (dpo - s);
