@@ -52,7 +52,7 @@ struct WgradArgs {
   int G, B, H;
   int tiles_wide, tiles_narrow;
   size_t split_stride;  // floats of partial tiles per split
-  const int64_t* tokens;
+  const int32_t* tok32;  // [N][G][16] token of (step, row group, row), -1 for rows past the batch (pmg_tok32_kernel)
   WJob jobs[WG_MAXJOBS];
   float* partial;     // [S][split_stride]
   float* rs_partial;  // [S][total_rs]
@@ -148,21 +148,15 @@ __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArg
 
 #define WG_LOAD_A(dst, k) \
   _Pragma("unroll") for (int i = 0; i < MI; ++i) dst[i] = pmg_bload(ars, voff, (unsigned)(k) * astr + arow[i]);
+  // token ids of the slab rows 4q..4q+3, one dwordx4 per lane from the per-slab table
+  const __amdgpu_buffer_rsrc_t trs = pmg_rsrc(reinterpret_cast<const float*>(a.tok32) + (size_t)sl0 * 16, (unsigned)nsafe * 64u);
   auto load_b = [&](int k, float4 (&fb)[NJ]) {
     if (!onehot) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) fb[j] = pmg_bload(brs, voff, (unsigned)k * bstr + brow[j]);
     } else {
-      const int sl = sl0 + k;
-      const int p = sl / G, g = sl - p * G;
-      int tk[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int row = g * 16 + 4 * q + c;
-        const int rc = row < a.B ? row : 0;
-        const int tv = (int)a.tokens[(size_t)p * a.B + rc];
-        tk[c] = row < a.B ? tv : -1;
-      }
+      const float4 tf = pmg_bload(trs, (unsigned)q * 16u, (unsigned)k * 64u);
+      const int tk[4] = {__float_as_int(tf.x), __float_as_int(tf.y), __float_as_int(tf.z), __float_as_int(tf.w)};
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int col = oh0 + 16 * j + n16;
@@ -226,6 +220,18 @@ __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArg
       const int r = r0 + 16 * i + n16;
       if (q == 0 && r < jb.rows) a.rs_partial[(size_t)s * a.total_rs + jb.rs0 + r] = v2;
     }
+  }
+}
+
+// tok32[p][g][r] = token fed at step p to row 16g+r (int32), -1 for rows past the batch.
+__global__ void pmg_tok32_kernel(const int64_t* __restrict__ tokens, int B, int G, int N, int32_t* __restrict__ out) {
+  const size_t total = (size_t)N * G * 16;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(idx & 15);
+    const size_t sl = idx >> 4;
+    const int p = (int)(sl / G), g = (int)(sl - (size_t)p * G);
+    const int row = g * 16 + r;
+    out[idx] = row < B ? (int32_t)tokens[(size_t)p * B + row] : -1;
   }
 }
 
@@ -474,7 +480,7 @@ size_t pmg_wgrad_acc_floats(const PmgDims& d) {
 size_t pmg_wgrad_partial_floats(const PmgDims& d) {
   JobPlan P;
   build_plan(d, &P);
-  return P.partial_floats + P.rs_partial_floats + 64;
+  return ((P.partial_floats + 63) & ~(size_t)63) + ((P.rs_partial_floats + 63) & ~(size_t)63) + (size_t)d.T * d.G * 16;
 }
 
 hipError_t pmg_run_wgrad(const PmgDims& d, const PmgLayout& lay, float* ws, const pmg_weights* wts,
@@ -483,10 +489,11 @@ hipError_t pmg_run_wgrad(const PmgDims& d, const PmgLayout& lay, float* ws, cons
   JobPlan P;
   build_plan(d, &P);
   WgradArgs& w = P.w;
-  w.tokens = tokens;
   w.dense = ws + lay.WG;
   w.partial = ws + lay.WGP;
   w.rs_partial = ws + lay.WGP + ((P.partial_floats + 63) & ~(size_t)63);
+  int32_t* tok32 = reinterpret_cast<int32_t*>(w.rs_partial + ((P.rs_partial_floats + 63) & ~(size_t)63));
+  w.tok32 = tok32;
   int k = 0;
   for (int l = 0; l < d.L; ++l) { w.jobs[k].A = ws + lay.DG[l]; w.jobs[k].B = ws + lay.HH[l]; ++k; }
   for (int l = 0; l < d.L; ++l) {
@@ -498,6 +505,14 @@ hipError_t pmg_run_wgrad(const PmgDims& d, const PmgLayout& lay, float* ws, cons
   w.jobs[k].A = ws + lay.DX; w.jobs[k].B = ws + lay.HH[d.L - 1]; ++k;
 
   hipError_t e = hipSuccess;
+  {
+    const size_t total = (size_t)(d.T - 1) * d.G * 16;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pmg_tok32_kernel, dim3(blocks), dim3(256), 0, st, tokens, d.B, d.G, d.T - 1, tok32);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
   {
     int nt[2][3] = {{0, 0, 0}, {0, 0, 0}};  // [wide][mode]
     for (int j = 0; j < w.njobs; ++j)
