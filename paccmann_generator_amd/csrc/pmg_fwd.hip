@@ -15,6 +15,10 @@
 //   h_new = (h_old - n) * z + n
 #include "pmg_kernels.h"
 
+#ifndef PMG_FWD_ILV
+#define PMG_FWD_ILV 1
+#endif
+
 namespace {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) {
@@ -152,6 +156,53 @@ __device__ __forceinline__ void gemm3_pass(f32x4 (&ar)[UPW], f32x4 (&az)[UPW], f
     at[u0 + uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[3 * uu + 2].C, x.C, at[u0 + uu], 0, 0, 0); \
   }
 #endif
+#if PMG_FWD_ILV
+  // Interleaved form: the six loads of the next set ride one by one in the shadow of the first six
+  // MFMAs of the current set (a block of loads holds the SIMD's issue port while the MFMA pipe
+  // drains; tests/microbench/gemm_loop.hip).
+#define PMG_MF1(wc, C, t)                                                                        \
+  {                                                                                              \
+    f32x4& acc_ = ((t) % 3 == 0) ? ar[u0 + (t) / 3] : ((t) % 3 == 1) ? az[u0 + (t) / 3] : at[u0 + (t) / 3]; \
+    acc_ = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[t].C, x.C, acc_, 0, 0, 0);                    \
+  }
+#define PMG_DGROUP(U, kgq)                                                                       \
+  {                                                                                              \
+    const int kg_ = (kgq);                                                                       \
+    const float4 xb = *reinterpret_cast<const float4*>(xrow + 16 * kg_ + 16);                    \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    side.template step<U>();                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    {                                                                                            \
+      const float4 x = xa;                                                                       \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                           \
+        PMG_MF1(wa, x, t)                                                                        \
+        wb[t] = pmg_bload(rs, voff, soff + t * ts + (unsigned)(kg_ + 1) * 1024u);                \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                       \
+      }                                                                                          \
+      PMG_STEP(wa, y) PMG_STEP(wa, z) PMG_STEP(wa, w)                                            \
+    }                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    {                                                                                            \
+      const bool more_ = kg_ + 2 < KG;                                                           \
+      const unsigned so_ = more_ ? soff + (unsigned)(kg_ + 2) * 1024u : nso;                     \
+      const unsigned ts_ = more_ ? ts : nts;                                                     \
+      float4 wn_[NT];                                                                            \
+      const float4 x = xb;                                                                       \
+      xa = *reinterpret_cast<const float4*>(xrow + 16 * (more_ ? kg_ + 2 : kg_));                \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                           \
+        PMG_MF1(wb, x, t)                                                                        \
+        wn_[t] = pmg_bload(rs, voff, so_ + t * ts_);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                       \
+      }                                                                                          \
+      PMG_STEP(wb, y) PMG_STEP(wb, z) PMG_STEP(wb, w)                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) wa[t] = wn_[t];                             \
+    }                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  }
+#else
 #define PMG_DGROUP(U, kgq)                                                                       \
   {                                                                                              \
     const int kg_ = (kgq);                                                                       \
@@ -179,6 +230,7 @@ __device__ __forceinline__ void gemm3_pass(f32x4 (&ar)[UPW], f32x4 (&az)[UPW], f
     }                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                           \
   }
+#endif
   if (!loaded) PMG_LOAD0(wa, 0)
   float4 xa = *reinterpret_cast<const float4*>(xrow);  // B operand, one half group ahead of its MFMAs
 #ifdef PMG_ABL_NOLOAD
@@ -194,6 +246,9 @@ __device__ __forceinline__ void gemm3_pass(f32x4 (&ar)[UPW], f32x4 (&az)[UPW], f
     for (int kg = 0; kg < KG; kg += 2) PMG_DGROUP(0, kg)
   }
 #undef PMG_DGROUP
+#if PMG_FWD_ILV
+#undef PMG_MF1
+#endif
 #undef PMG_STEP
 #undef PMG_LOAD
 #undef PMG_LOAD0
