@@ -29,28 +29,32 @@ __device__ __forceinline__ f32x4 bl4(__amdgpu_buffer_rsrc_t r, unsigned voff, un
   f32x4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; return o;
 }
 
-// acc[t] += Wt[tile t][groups of this chunk] * chunk columns.  24 reduction groups:
-// 8 per piece; pcN = LDS column block (of 128) holding piece N of this product.
-// Weights through the buffer resource (voff = lane*16, soff = first tile, first group of the
-// chunk, ts = bytes per tile).  Two register sets + sched_barriers keep the next group's
-// loads in flight under the current group's MFMAs.
+// acc[t] += Wt[tile t][24 groups per chunk] * chunk columns.  24 reduction groups per chunk: 8 per
+// piece; pcN = LDS column block (of 128) holding piece N of this product.  Weights through the
+// buffer resource (voff = lane*16, soff = first tile, first group, ts = bytes per tile).  Two
+// register sets + sched_barriers keep the next group's loads in flight under the current MFMAs.
+// The same product over `nch` consecutive chunks (chunk buffers 16*PMG_CP floats apart, weights
+// contiguous: 24 groups per chunk) as ONE software-pipelined reduction: one exposed weight load at
+// the start instead of one per chunk.
 template <int NT>
-__device__ __forceinline__ void gemm_chunk(f32x4 (&acc)[NT], const __amdgpu_buffer_rsrc_t rs, const unsigned voff,
-                                           const unsigned soff, const unsigned ts, const float* xb, const int pc0,
-                                           const int pc1, const int pc2) {
+__device__ __forceinline__ void gemm_chunks(f32x4 (&acc)[NT], const __amdgpu_buffer_rsrc_t rs, const unsigned voff,
+                                            const unsigned soff, const unsigned ts, const float* xb, const int nch,
+                                            const int pc0, const int pc1, const int pc2) {
   float4 wa[NT], wb[NT];
+  const int nrg = 24 * nch;
 #define PMG_LOAD(dst, rgi) \
   _Pragma("unroll") for (int t = 0; t < NT; ++t) dst[t] = pmg_bload(rs, voff, soff + t * ts + (unsigned)(rgi) * 1024u);
 #define PMG_STEP(wc, C)                                                                  \
   _Pragma("unroll") for (int t = 0; t < NT; ++t)                                         \
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[t].C, x.C, acc[t], 0, 0, 0);
   PMG_LOAD(wa, 0)
+  int cc = 0, rg = 0;  // chunk and group inside the chunk of the running index
 #pragma unroll 1
-  for (int rg = 0; rg < 24; rg += 2) {
+  for (int rgl = 0; rgl < nrg; rgl += 2) {
     const int piece = rg >> 3;
     const int pc = (piece == 0) ? pc0 : (piece == 1) ? pc1 : pc2;
-    const float* xp = xb + pc * PMG_CHUNK + (rg & 7) * 16;
-    PMG_LOAD(wb, rg + 1)
+    const float* xp = xb + (size_t)cc * 16 * PMG_CP + pc * PMG_CHUNK + (rg & 7) * 16;
+    PMG_LOAD(wb, rgl + 1)
     __builtin_amdgcn_sched_barrier(0);
     {
       const float4 x = *reinterpret_cast<const float4*>(xp);
@@ -58,7 +62,7 @@ __device__ __forceinline__ void gemm_chunk(f32x4 (&acc)[NT], const __amdgpu_buff
     }
     __builtin_amdgcn_sched_barrier(0);
     {
-      const int rn = (rg + 2 < 24) ? rg + 2 : rg;
+      const int rn = (rgl + 2 < nrg) ? rgl + 2 : rgl;
       PMG_LOAD(wa, rn)
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -67,6 +71,8 @@ __device__ __forceinline__ void gemm_chunk(f32x4 (&acc)[NT], const __amdgpu_buff
       PMG_STEP(wb, x) PMG_STEP(wb, y) PMG_STEP(wb, z) PMG_STEP(wb, w)
     }
     __builtin_amdgcn_sched_barrier(0);
+    rg += 2;
+    if (rg == 24) { rg = 0; ++cc; }
   }
 #undef PMG_STEP
 #undef PMG_LOAD
@@ -235,21 +241,21 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
           PMG_TICK(0)
           __syncthreads();
           PMG_TICK(1)
-#pragma unroll
-          for (int cc = 0; cc < NCB; ++cc) {
-            const int c = rd * NCB + cc;
-            // ---- products over this chunk's 3*128 reduction rows
-            const float* xb = cb + (size_t)cc * 16 * PMG_CP + b * PMG_CP + 4 * q;
+          {
+            // ---- products over the 3*128 reduction rows of each of this round's chunks, one
+            // continuous reduction per product
+            const float* xb = cb + b * PMG_CP + 4 * q;
+            const unsigned c0 = (unsigned)(rd * NCB);
             {
-              const unsigned so = a.oWHHt[l] + ((unsigned)(wave * UPW) * KG3 + (unsigned)c * 24u) * 1024u;
-              if (!(dbg & 0x400)) gemm_chunk<UPW>(acc_hh, wrs, voff, so, KG3 * 1024u, xb, 0, 1, 3);
+              const unsigned so = a.oWHHt[l] + ((unsigned)(wave * UPW) * KG3 + c0 * 24u) * 1024u;
+              if (!(dbg & 0x400)) gemm_chunks<UPW>(acc_hh, wrs, voff, so, KG3 * 1024u, xb, NCB, 0, 1, 3);
             }
             if (MULTI && l > 0) {
-              const unsigned so = a.oWIHt[l] + ((unsigned)(wave * UPW) * KG3 + (unsigned)c * 24u) * 1024u;
-              gemm_chunk<UPW>(acc_dx, wrs, voff, so, KG3 * 1024u, xb, 0, 1, 2);
+              const unsigned so = a.oWIHt[l] + ((unsigned)(wave * UPW) * KG3 + c0 * 24u) * 1024u;
+              gemm_chunks<UPW>(acc_dx, wrs, voff, so, KG3 * 1024u, xb, NCB, 0, 1, 2);
             } else if (wave < PMG_KS / 16) {
-              const unsigned so = a.oWIHt[0] + ((unsigned)wave * KG3 + (unsigned)c * 24u) * 1024u;
-              if (!(dbg & 0x800)) gemm_chunk<1>(acc_top, wrs, voff, so, KG3 * 1024u, xb, 0, 1, 2);
+              const unsigned so = a.oWIHt[0] + ((unsigned)wave * KG3 + c0 * 24u) * 1024u;
+              if (!(dbg & 0x800)) gemm_chunks<1>(acc_top, wrs, voff, so, KG3 * 1024u, xb, NCB, 0, 1, 2);
             }
           }
           PMG_TICK(2)
