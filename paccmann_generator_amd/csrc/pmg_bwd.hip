@@ -15,6 +15,10 @@
 // The algorithm is restated line by line in oracle/fused_model.py (forward_backward).
 #include "pmg_kernels.h"
 
+#ifndef PMG_BWD_XPRE
+#define PMG_BWD_XPRE 1
+#endif
+
 namespace {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) {
@@ -49,6 +53,40 @@ __device__ __forceinline__ void gemm_chunks(f32x4 (&acc)[NT], const __amdgpu_buf
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[t].C, x.C, acc[t], 0, 0, 0);
   PMG_LOAD(wa, 0)
   int cc = 0, rg = 0;  // chunk and group inside the chunk of the running index
+#if PMG_BWD_XPRE
+  // B operand (LDS) one half group ahead of its MFMAs
+  const float* xp = xb + pc0 * PMG_CHUNK;
+  float4 xa = *reinterpret_cast<const float4*>(xp);
+#pragma unroll 1
+  for (int rgl = 0; rgl < nrg; rgl += 2) {
+    PMG_LOAD(wb, rgl + 1)
+    const float4 xn = *reinterpret_cast<const float4*>(xp + 16);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const float4 x = xa;
+      PMG_STEP(wa, x) PMG_STEP(wa, y) PMG_STEP(wa, z) PMG_STEP(wa, w)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int rn = (rgl + 2 < nrg) ? rgl + 2 : rgl;
+      PMG_LOAD(wa, rn)
+      if (rgl + 2 < nrg) {
+        rg += 2;
+        if (rg == 24) { rg = 0; ++cc; }
+      }
+      const int piece = rg >> 3;
+      const int pc = (piece == 0) ? pc0 : (piece == 1) ? pc1 : pc2;
+      xp = xb + (size_t)cc * 16 * PMG_CP + pc * PMG_CHUNK + (rg & 7) * 16;
+      xa = *reinterpret_cast<const float4*>(xp);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const float4 x = xn;
+      PMG_STEP(wb, x) PMG_STEP(wb, y) PMG_STEP(wb, z) PMG_STEP(wb, w)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#else
 #pragma unroll 1
   for (int rgl = 0; rgl < nrg; rgl += 2) {
     const int piece = rg >> 3;
@@ -74,6 +112,7 @@ __device__ __forceinline__ void gemm_chunks(f32x4 (&acc)[NT], const __amdgpu_buf
     rg += 2;
     if (rg == 24) { rg = 0; ++cc; }
   }
+#endif
 #undef PMG_STEP
 #undef PMG_LOAD
 }
