@@ -147,8 +147,12 @@ class Reinforce(object):
         if table is not None:
             tokens, lens = self.sample_tokens(latent)
             strings = ops.detokenize(table, tokens, lens)
-            padded = pad_rows_on_device(tokens, lens, lang.stop_index, t_max=tokens.shape[1] + 2).t().cpu()
-            numericals = [padded[i, :n + 2] for i, n in enumerate(lens.cpu().tolist())]
+            # rows + 2 x stop, cut out of one device-built matrix: one masked select, one copy to the
+            # host, one split (B Python-level slices cost more than the decode itself at B=4096)
+            padded = pad_rows_on_device(tokens, lens, lang.stop_index, t_max=tokens.shape[1] + 2).t()
+            sizes = lens.to(torch.int64) + 2
+            keep_pos = torch.arange(padded.shape[1], device=padded.device).unsqueeze(0) < sizes.unsqueeze(1)
+            numericals = list(padded[keep_pos].cpu().split(sizes.cpu().tolist()))
             self._last_sample = (tokens, lens, numericals)      # lets _policy_gradient pad on the device
         else:
             mols_numerical = self.generator.generate(
