@@ -218,7 +218,12 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-phases', action='store_true')
     ap.add_argument('--seqs', type=int, default=65536, help='cfg5: pre-sampled sequences per step (1M = 1048576)')
+    ap.add_argument('--allow-variant', action='store_true',
+                    help='permit a tuning build selected by PMG_LIB (ablation / profile variants give wrong or '
+                         'slower results; the default library is the only one whose numbers count)')
     args = ap.parse_args()
+    if os.environ.get('PMG_LIB') and not args.allow_variant:
+        raise SystemExit('bench.py: PMG_LIB selects a non-default library; pass --allow-variant to time it')
     if os.environ.get('PMG_HANG_DUMP'):  # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ['PMG_HANG_DUMP']), exit=True)

@@ -34,7 +34,7 @@ extern "C" {
 
 /* flags */
 #define PMG_FLAG_NO_EARLY_EXIT 1u /* decode: run all gen_len steps even after every row hit stop */
-#define PMG_FLAG_ACCUMULATE 2u    /* bwd: add into grad_out instead of overwriting it */
+#define PMG_FLAG_ACCUMULATE 2u    /* bwd: add into grad_out AND loss_out instead of overwriting them (chunked batches) */
 #define PMG_FLAG_SKIP_WGRAD 4u    /* bwd, profiling aid: run the time recurrence only (grad_out untouched) */
 #define PMG_FLAG_ONLY_WGRAD 8u    /* bwd, profiling aid: redo the weight-gradient GEMM of the previous call */
 
@@ -103,7 +103,7 @@ int pmg_workspace_bytes(const pmg_shape* s, int mode, size_t* out);
  * argmax (GreedySearch).  Draws use Philox4x32-10 keyed by philox_seed with counter
  * (seq_index_base + row, philox_offset + step), so a batch sharded over GPUs samples
  * the same tokens as the unsharded batch.
- *   latent     [B,Z]
+ *   latent     [B,Z]   (w->b_l2h must be 16-byte aligned; 0 <= start_tok, stop_tok < V)
  *   tokens_out [B,gen_len] every sampled token (start token not included)
  *   len_out    [B] tokens before the first stop_tok (gen_len if none): the crop
  *              TeacherVAE.generate applies (consumed at reinforce.py:172-187)
@@ -135,8 +135,9 @@ int pmg_logprob_fwd(const pmg_shape* s, const pmg_weights* w, const int64_t* tok
  *   reward   [B]
  *   grad_out gradients of every decoder parameter reachable from the loss
  *            (latent_to_hidden is reached through grad_h0 by the caller's autograd)
- *   grad_h0  [L,B,H]
- *   loss_out [1] */
+ *   grad_h0  [L,B,H], 16-byte aligned
+ *   loss_out [1]; with PMG_FLAG_ACCUMULATE the call's loss is added to it, like the gradients
+ * Token ids outside [0,V) are clamped by the kernels (memory safety only; validate on the host). */
 int pmg_reinforce_bwd(const pmg_shape* s, const pmg_weights* w, const int64_t* tokens,
                       const float* reward, float scale, uint32_t flags,
                       const pmg_grads* grad_out, float* grad_h0, float* loss_out,

@@ -4,11 +4,18 @@
 #include <string.h>
 #include <stdlib.h>
 
-// PMG_DEBUG=<hex>: ablation bits for timing experiments (skip a phase of the kernels).
+// Ablation bits for timing experiments (skip a phase of the kernels; results are wrong when set)
+// exist only in -DPMG_ABLATE builds (tuning variants made by __graft_entry__.build(extra_flags=...,
+// libname=...)).  The default library reads no environment variable and its kernels carry no
+// ablation branches (PMG_DBG() is the constant 0 there).
+#ifdef PMG_ABLATE
 static int debug_bits() {
   const char* e = getenv("PMG_DEBUG");
   return e ? (int)strtol(e, nullptr, 16) : 0;
 }
+#else
+static int debug_bits() { return 0; }
+#endif
 
 // implemented in pmg_wgrad.hip
 struct WgradArgs;
@@ -76,7 +83,7 @@ extern "C" const char* pmg_strerror(int code) {
     case PMG_E_STACK: return "unsupported stack: need 1<=W<=64, 2<=D";
     case PMG_E_VOCAB: return "unsupported vocabulary: need 3+W+V<=256";
     case PMG_E_LAYERS: return "unsupported n_layers: need 1<=L<=4";
-    case PMG_E_ALIGN: return "pointer not 16-byte aligned";
+    case PMG_E_ALIGN: return "pointer not 16-byte aligned (b_l2h of pmg_decode, grad_h0 of pmg_reinforce_bwd)";
     case PMG_E_MODE: return "unknown workspace mode";
     case PMG_E_ARG: return "bad argument";
     case PMG_E_LDS: return "shape needs more than 160 KiB of LDS per workgroup";
@@ -114,6 +121,8 @@ extern "C" int pmg_workspace_bytes(const pmg_shape* s, int mode, size_t* out) {
 static float* ws_base(void* ws) {
   return reinterpret_cast<float*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
 }
+
+static bool misaligned16(const void* p) { return ((uintptr_t)p & 15u) != 0; }
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
@@ -198,7 +207,8 @@ extern "C" int pmg_decode(const pmg_shape* s, const pmg_weights* w, const float*
   if (!latent || !tokens_out || !len_out || !ws) return PMG_E_NULL;
   if ((rc = check_weights(s, w, true))) return rc;
   if (gen_len < 1 || gen_len != s->T) return PMG_E_ARG;
-  if (start_tok < 0 || start_tok >= s->V) return PMG_E_ARG;
+  if (start_tok < 0 || start_tok >= s->V || stop_tok < 0 || stop_tok >= s->V) return PMG_E_ARG;
+  if (misaligned16(w->b_l2h)) return PMG_E_ALIGN;  // read with 16-byte loads
   hipStream_t st = (hipStream_t)stream;
   const PmgDims d = pmg_dims(s);
   PmgLayout lay;
@@ -250,6 +260,7 @@ extern "C" int pmg_logprob_fwd(const pmg_shape* s, const pmg_weights* w, const i
 extern "C" int pmg_step(const pmg_shape* s, const pmg_weights* w, const int64_t* tok, const float* hidden_in,
                         const float* stack_in, float* hidden_out, float* stack_out, float* logits_out, void* ws,
                         pmg_stream stream) {
+  if (!s) return PMG_E_NULL;
   pmg_shape s1 = *s;
   s1.T = 1;
   if (s1.Z < 32 || s1.Z % 32) s1.Z = 32;  // latent_to_hidden is not used by a step
@@ -285,6 +296,7 @@ extern "C" int pmg_reinforce_bwd(const pmg_shape* s, const pmg_weights* w, const
     return PMG_E_NULL;
   for (int l = 0; l < s->L; ++l)
     if (!grad_out->w_ih[l] || !grad_out->w_hh[l] || !grad_out->b_ih[l] || !grad_out->b_hh[l]) return PMG_E_NULL;
+  if (misaligned16(grad_h0)) return PMG_E_ALIGN;  // written with 16-byte stores
   hipStream_t st = (hipStream_t)stream;
   const PmgDims d = pmg_dims(s);
   PmgLayout lay;

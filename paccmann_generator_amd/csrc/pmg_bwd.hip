@@ -142,7 +142,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int H = a.H, XP = a.XP, W = a.W, D = a.D, V = a.V, L = a.L, B = a.B, G = a.G, N = a.N;
   const int UT = H / 16, NXT = a.NXT;
-  const int dbg = a.dbg;
+  const int dbg = PMG_DBG(a.dbg);
   float* cb = reinterpret_cast<float*>(smem);   // [NCB][16][PMG_CP], NCB = min(H/128, 4)
   float* dxl = cb + (UPW < 4 ? UPW : 4) * 16 * PMG_CP;            // [16][XP]   dctrl | dpush | dlogits
   float* dtl = dxl + 16 * XP;                   // [16][PMG_XTP] dtop

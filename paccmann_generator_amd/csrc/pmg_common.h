@@ -24,6 +24,17 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// -DPMG_PROFILE (in-kernel cycle counters) implies -DPMG_ABLATE (phase-skipping bits); neither is
+// part of the default library.
+#if defined(PMG_PROFILE) && !defined(PMG_ABLATE)
+#define PMG_ABLATE 1
+#endif
+#ifdef PMG_ABLATE
+#define PMG_DBG(x) (x)
+#else
+#define PMG_DBG(x) 0
+#endif
+
 // error codes (negative returns of the C ABI)
 enum {
   PMG_OK = 0,

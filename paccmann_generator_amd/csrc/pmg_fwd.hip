@@ -368,8 +368,8 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
   constexpr bool teacher = (MODE == PMG_FWD_TEACHER);
   constexpr bool decode = (MODE == PMG_FWD_DECODE);
   constexpr bool stepm = (MODE == PMG_FWD_STEP);
-  const bool keep = teacher && !(a.dbg & 0x1000);  // keep per-step history for the backward
-  const int dbg = a.dbg;
+  const bool keep = teacher && !(PMG_DBG(a.dbg) & 0x1000);  // keep per-step history for the backward
+  const int dbg = PMG_DBG(a.dbg);
 
   // ---------------------------------------------------------------- init
   for (int idx = tid; idx < 16 * PMG_XTP; idx += NTHR) xtop[idx] = 0.0f;
@@ -398,7 +398,8 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
   }
   if (tid < 16) {
     int t0 = a.start_tok;
-    if (!decode) t0 = (row0 + tid < B) ? (int)a.tok_in[row0 + tid] : 0;
+    // ids outside [0,V) are clamped (memory safety only: callers validate, ops.reinforce_loss does)
+    if (!decode) t0 = (row0 + tid < B) ? min(max((int)a.tok_in[row0 + tid], 0), V - 1) : 0;
     misc[tid] = t0;
   }
   bool s_zero = true;  // stack entering step 0 is all zeros
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
     const bool st_on = st_col && st_d0 < st_d1 && !(dbg & 0x100) && i < N;
     // target token of step i-1 (teacher): requested here, used after the extras GEMM
     int cs_y = 0;
-    if (teacher && i >= 1 && row0 + cs_bb < B) cs_y = (int)a.tok_in[(size_t)i * B + row0 + cs_bb];
+    if (teacher && i >= 1 && row0 + cs_bb < B) cs_y = min(max((int)a.tok_in[(size_t)i * B + row0 + cs_bb], 0), V - 1);
 
     // old rows d0-1, d0, d0+1 (first row of this thread) and the ring d0+2 .. d0+5: requested here,
     // unconditionally at clamped rows (inactive threads read row 0 of their column), masked when used

@@ -44,7 +44,7 @@ hipError_t pmg_launch_aux(const AuxArgs* a, hipStream_t st);
 
 struct FwdArgs {
   int mode;   // PMG_FWD_*
-  int dbg;    // PMG_DEBUG ablation bits (timing experiments only; results are wrong when set)
+  int dbg;    // ablation bits, -DPMG_ABLATE builds only (always 0 in the default library)
   int B, G, N;  // N decoder steps
   int H, W, D, V, L, Z, NX, NXT, XP, HP, KGH, VP, SW;
   int start_tok, stop_tok;
@@ -84,7 +84,7 @@ size_t pmg_fwd_lds_bytes(const FwdArgs* a);
 struct BwdArgs {
   int B, G, N;  // N = T-1 decoder steps
   int H, W, D, V, L, NX, NXT, XP, KGH, VP, SW, UPW;
-  int dbg;      // PMG_DEBUG ablation bits
+  int dbg;      // ablation bits, -DPMG_ABLATE builds only
   float scale;
   const int64_t* tokens;  // [T][B]
   const float* reward;    // [B]

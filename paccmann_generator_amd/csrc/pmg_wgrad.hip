@@ -350,7 +350,7 @@ __global__ void pmg_finalize_kernel(const FinArgs a) {
     // the loss
     float s = 0.0f;
     for (int g = 0; g < a.G; ++g) s += a.lossp[g];
-    *a.loss_out = s;
+    put(a.loss_out, s, a.accumulate);
   }
 }
 

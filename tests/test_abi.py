@@ -93,3 +93,16 @@ def test_cpu_tensors_are_rejected_not_routed_elsewhere():
     from paccmann_generator_amd import _ffi
     with pytest.raises(_ffi.PmgError):
         _ffi._ptr(torch.zeros(4))
+
+
+def test_default_library_has_no_ablation_switches():
+    """The shipped libpmg.so reads no environment variable: the phase-skipping bits of the timing
+    experiments exist only in -DPMG_ABLATE / -DPMG_PROFILE variant builds."""
+    from paccmann_generator_amd import _ffi
+    default = os.path.join(ROOT, 'paccmann_generator_amd', 'lib', 'libpmg.so')
+    blob = open(default, 'rb').read()
+    assert b'PMG_DEBUG' not in blob
+    import subprocess
+    syms = subprocess.run(['nm', '-D', '--undefined-only', default], capture_output=True, text=True).stdout
+    assert 'getenv' not in syms
+    assert os.path.samefile(_ffi.LIB_PATH, default) or os.environ.get('PMG_LIB')
