@@ -115,6 +115,23 @@ int pmg_decode(const pmg_shape* s, const pmg_weights* w, const float* latent,
                uint32_t flags, int64_t* tokens_out, int32_t* len_out,
                void* ws, pmg_stream stream);
 
+/* pmg_decode for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE: it is
+ * pmg_decode with the workspace argument replaced by a 32 MiB static device array inside the
+ * library (pmg_noalloc_scratch_bytes()), which every GPU the library runs on holds until the process
+ * ends.  Shapes whose pmg_workspace_bytes(s, PMG_MODE_DECODE) exceed that size are rejected with a
+ * negative code (at the configs[1] model shape: up to 1328 sequences per call).  Calls no
+ * hipMalloc/hipFree or any allocating routine; same results as pmg_decode, bit for bit.  All calls
+ * on one GPU share that GPU's array: calls that overlap on one GPU (different streams or threads)
+ * race; calls ordered on one stream are safe. */
+int pmg_decode_noalloc(const pmg_shape* s, const pmg_weights* w, const float* latent,
+                       int start_tok, int stop_tok, int gen_len, float temperature,
+                       uint64_t philox_seed, uint64_t philox_offset, int64_t seq_index_base,
+                       uint32_t flags, int64_t* tokens_out, int32_t* len_out, pmg_stream stream);
+
+/* Size in bytes of the static scratch array behind pmg_decode_noalloc. */
+size_t pmg_noalloc_scratch_bytes(void);
+
 /* Teacher-forced trajectory log-probs -- replaces the loop at
  * reinforce_omics.py:319-329 (reinforce_proteins.py:307-318): zero stack, then for
  * p in 0..T-2: decoder(tokens[p], hidden, stack); output_layer; log_softmax;

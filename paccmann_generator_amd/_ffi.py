@@ -55,6 +55,7 @@ class PmgGrads(C.Structure):
 EXPORTS = (
     'pmg_abi_version', 'pmg_strerror', 'pmg_check_shape', 'pmg_workspace_bytes',
     'pmg_decode', 'pmg_logprob_fwd', 'pmg_reinforce_bwd', 'pmg_step', 'pmg_detokenize',
+    'pmg_decode_noalloc', 'pmg_noalloc_scratch_bytes',
 )
 
 
@@ -87,8 +88,11 @@ def _load():
     lib.pmg_detokenize.argtypes = [
         C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.pmg_decode_noalloc.argtypes = lib.pmg_decode.argtypes[:-2] + [C.c_void_p]
+    lib.pmg_noalloc_scratch_bytes.argtypes = []
     for name in EXPORTS[2:]:
         getattr(lib, name).restype = C.c_int
+    lib.pmg_noalloc_scratch_bytes.restype = C.c_size_t
     if lib.pmg_abi_version() != PMG_ABI_VERSION:
         raise ImportError('libpmg.so ABI version mismatch')
     return lib

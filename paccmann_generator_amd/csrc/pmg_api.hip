@@ -3,6 +3,7 @@
 #include "pmg_kernels.h"
 #include <string.h>
 #include <stdlib.h>
+#include <mutex>
 
 // Ablation bits for timing experiments (skip a phase of the kernels; results are wrong when set)
 // exist only in -DPMG_ABLATE builds (tuning variants made by __graft_entry__.build(extra_flags=...,
@@ -87,6 +88,7 @@ extern "C" const char* pmg_strerror(int code) {
     case PMG_E_MODE: return "unknown workspace mode";
     case PMG_E_ARG: return "bad argument";
     case PMG_E_LDS: return "shape needs more than 160 KiB of LDS per workgroup";
+    case PMG_E_SCRATCH: return "shape needs more scratch than the 32 MiB static array of pmg_decode_noalloc holds";
   }
   return code > 0 ? "HIP runtime error (see hipGetErrorString)" : "unknown error";
 }
@@ -227,6 +229,52 @@ extern "C" int pmg_decode(const pmg_shape* s, const pmg_weights* w, const float*
   a.tok_out = tokens_out; a.len_out = len_out;
   HIPCHK(pmg_launch_fwd(&a, st));
   return PMG_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// pmg_decode_noalloc: pmg_decode on a workspace that is a static device array, for callers that
+// cannot allocate (HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+// Every GPU the library runs on holds its own copy of the array at its own address; the address is
+// looked up once per device, with that device current, and only that pointer is ever handed to
+// kernels (the array's name is a host-side stand-in, not a device address).
+// ---------------------------------------------------------------------------------
+#define PMG_NOALLOC_SCRATCH_BYTES ((size_t)32 << 20)
+#define PMG_NOALLOC_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[PMG_NOALLOC_SCRATCH_BYTES];
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[PMG_NOALLOC_MAX_DEVICES];  // per device, filled on the first call on that device
+
+static int scratch_for_current_device(void** out) {
+  int dev = -1;
+  HIPCHK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= PMG_NOALLOC_MAX_DEVICES) return PMG_E_ARG;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return PMG_E_NULL;
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return PMG_OK;
+}
+
+extern "C" size_t pmg_noalloc_scratch_bytes(void) { return PMG_NOALLOC_SCRATCH_BYTES; }
+
+extern "C" int pmg_decode_noalloc(const pmg_shape* s, const pmg_weights* w, const float* latent, int start_tok,
+                                  int stop_tok, int gen_len, float temperature, uint64_t philox_seed,
+                                  uint64_t philox_offset, int64_t seq_index_base, uint32_t flags,
+                                  int64_t* tokens_out, int32_t* len_out, pmg_stream stream) {
+  size_t need = 0;
+  int rc = pmg_workspace_bytes(s, PMG_MODE_DECODE, &need);
+  if (rc) return rc;
+  if (need > PMG_NOALLOC_SCRATCH_BYTES) return PMG_E_SCRATCH;
+  void* ws = nullptr;
+  if ((rc = scratch_for_current_device(&ws))) return rc;
+  // Nothing in the decode workspace has to start at zero: the packed weights are rewritten by every
+  // call and stack rows are only read after this call wrote them (rows never written are masked).
+  return pmg_decode(s, w, latent, start_tok, stop_tok, gen_len, temperature, philox_seed, philox_offset,
+                    seq_index_base, flags, tokens_out, len_out, ws, stream);
 }
 
 static void fill_history(FwdArgs* a, const PmgDims& d, const PmgLayout& lay, float* base) {

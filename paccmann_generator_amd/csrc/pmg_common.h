@@ -48,6 +48,7 @@ enum {
   PMG_E_MODE = -8,
   PMG_E_ARG = -9,
   PMG_E_LDS = -10,
+  PMG_E_SCRATCH = -11,
 };
 
 // Derived dimensions, identical on host and device.

@@ -20,7 +20,8 @@ def declared_functions():
 def test_header_declares_the_expected_entry_points():
     assert declared_functions() == sorted([
         'pmg_abi_version', 'pmg_strerror', 'pmg_check_shape', 'pmg_workspace_bytes', 'pmg_decode',
-        'pmg_logprob_fwd', 'pmg_reinforce_bwd', 'pmg_step', 'pmg_detokenize'])
+        'pmg_logprob_fwd', 'pmg_reinforce_bwd', 'pmg_step', 'pmg_detokenize', 'pmg_decode_noalloc',
+        'pmg_noalloc_scratch_bytes'])
 
 
 def test_library_exports_every_declared_symbol():
