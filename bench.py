@@ -13,9 +13,9 @@ A "step" = one pass of the hot path over one batch of synthetic latents
 Rewards are synthetic and resident (RDKit scoring stays on the host and is not part of
 the step).  Random-init weights, synthetic latents.
 
-Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 via
-python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
-Rank 0 prints ONE JSON line.
+Launch: python bench.py [--gpus N --steps K --warmup W].  With N>1 and no WORLD_SIZE in the
+environment it starts its own N ranks (python -m torch.distributed.run --nproc-per-node N ...);
+launched under torch.distributed.run it is one of the ranks.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -38,8 +38,10 @@ CONFIGS = {
                  n_layers=1, latent_dim=256, pad_index=0, batch=64, length=100),
     'cfg2': dict(embedding_size=128, rnn_cell_size=512, vocab_size=60, stack_width=50, stack_depth=50,
                  n_layers=1, latent_dim=256, pad_index=0, batch=4096, length=128),
+    # configs[3] at its stated size; the training pair runs as 4 chunks of 4096 sequences whose gradients
+    # accumulate (ops.plan_chunks: 80 GB of history per chunk)
     'cfg4': dict(embedding_size=128, rnn_cell_size=1024, vocab_size=60, stack_width=50, stack_depth=50,
-                 n_layers=2, latent_dim=256, pad_index=0, batch=4096, length=256),
+                 n_layers=2, latent_dim=256, pad_index=0, batch=16384, length=256),
     # configs[4]: teacher-forced log-prob + BPTT only, over pre-sampled sequences in chunks of `batch`
     'cfg5': dict(embedding_size=128, rnn_cell_size=512, vocab_size=60, stack_width=50, stack_depth=50,
                  n_layers=1, latent_dim=256, pad_index=0, batch=4096, length=128),
@@ -156,6 +158,11 @@ def time_phases(learner, cfg, latent, rewards, B, reps=3):
     dec = learner.generator.decoder
     w = dec.weights()
     T = cfg['length']
+    # batches beyond the workspace budget run as chunks: time the kernels on one chunk
+    lo, hi = ops.plan_chunks(w.dims, B, T + 2)[0]
+    if hi - lo < B:
+        B = hi - lo
+        latent, rewards = latent[:, :B].contiguous(), rewards[:B].contiguous()
 
     def timed(fn):
         fn()
@@ -192,7 +199,7 @@ def time_phases(learner, cfg, latent, rewards, B, reps=3):
 
     def f_fwd():
         _ffi.check(_ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(h0),
-                                            _ffi._ptr(logp), None, _ffi._ptr(ws), st), 'fwd')
+                                            _ffi._ptr(logp), None, 0, _ffi._ptr(ws), st), 'fwd')
 
     def f_bwd(flags):
         def f():
@@ -204,6 +211,7 @@ def time_phases(learner, cfg, latent, rewards, B, reps=3):
     out['bptt'] = timed(f_bwd(_ffi.PMG_FLAG_SKIP_WGRAD))
     out['wgrad'] = timed(f_bwd(_ffi.PMG_FLAG_ONLY_WGRAD))
     out['_steps'] = dict(decode=T, teacher_fwd=Tt - 1, bptt=Tt - 1, wgrad=Tt - 1)
+    out['_batch'] = B
     del ws
     return out
 
@@ -228,15 +236,28 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ['PMG_HANG_DUMP']), exit=True)
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # Called as plain `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU,
+        # as children of a process that has not touched the GPU (importing torch does not), and leave
+        # with their exit code.  Rank 0's JSON line goes to our stdout.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch N>1 with torch.distributed.run (one rank per GPU)')
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
     import torch.distributed as dist
     pg = None
-    if world > 1:
+    if 'WORLD_SIZE' in os.environ and (world > 1 or os.environ.get('PMG_DIST_SINGLE')):
+        # PMG_DIST_SINGLE=1 under a one-rank torch.distributed.run: the N>1 code path (process group,
+        # RCCL all-reduce of the flat gradient buffer) with world size 1, for a box with one GPU
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # RCCL ("nccl" on ROCm) over xGMI.  PMG_DIST_BACKEND=gloo rehearses the N>1 code path on a
         # box with fewer GPUs than ranks (ranks then share devices; timing is meaningless there).
@@ -265,7 +286,8 @@ def main():
     def step():
         tokens, lens = learner.sample_tokens(latent, seq_index_base=rank * B, early_exit=False)
         padded = pad_rows_on_device(tokens, lens, STOP, t_max=T + 2)
-        learner.learn(latent, padded, valid_idx, rewards, lrps=1, n_valid_global=B * world)
+        learner._tokens_trusted = True      # rows come straight from pmg_decode
+        learner.learn(latent, padded, valid_idx, rewards, lrps=1)
 
     tokens_per_step = B * T
     if args.config == 'cfg5':
@@ -282,9 +304,9 @@ def main():
             for c in range(n_chunks):
                 h0 = dec.latent_to_hidden(latent.repeat(dec.n_layers, 1, 1))
                 loss, _ = ops.reinforce_loss(dec.weights(), chunks[c % len(chunks)], h0, rewards,
-                                             1.0 / (n_chunks * B * world))
+                                             1.0 / (n_chunks * B * world), trusted_tokens=True)
                 loss.backward()
-            if world > 1:
+            if pg is not None:
                 dp.all_reduce_gradients_(dec.parameters())
             torch.nn.utils.clip_grad_norm_(list(dec.parameters()), 0.1)
             learner.optimizer.step()
@@ -292,18 +314,18 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if pg is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if pg is not None:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if world > 1:
+    if pg is not None:
         t = torch.tensor([el], device=device, dtype=torch.float64)
         dp.all_reduce_(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -330,17 +352,19 @@ def main():
         if not args.no_phases:
             ph = time_phases(learner, cfg, latent, rewards, B)
             steps = ph.pop('_steps')
+            Bp = ph.pop('_batch')      # sequences per kernel launch (one chunk when the batch is chunked)
             dom = max(ph, key=lambda k: ph[k])
-            ach = B * steps[dom] * F / (ph[dom] * 1e-3) / 1e12
+            ach = Bp * steps[dom] * F / (ph[dom] * 1e-3) / 1e12
             result['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
                                   'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
-                                  'traffic': pmc_traffic(args.config, B, dom), 'ms': ph[dom]}
+                                  'traffic': pmc_traffic(args.config, Bp, dom), 'ms': ph[dom],
+                                  'sequences_per_launch': Bp}
             result['phase_ms'] = ph
-            result['phase_tflops'] = {k: B * steps[k] * F / (v * 1e-3) / 1e12 for k, v in ph.items()}
+            result['phase_tflops'] = {k: Bp * steps[k] * F / (v * 1e-3) / 1e12 for k, v in ph.items()}
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if pg is not None:
         # replicas must still be identical after the steps (no broadcast is ever done)
         flat = torch.cat([p.detach().reshape(-1) for p in learner.generator.decoder.parameters()])
         lo, hi = flat.clone(), flat.clone()

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define PMG_MAX_LAYERS 4
-#define PMG_ABI_VERSION 1
+#define PMG_ABI_VERSION 2
 
 /* workspace modes */
 #define PMG_MODE_DECODE 0 /* pmg_decode */
@@ -37,6 +37,9 @@ extern "C" {
 #define PMG_FLAG_ACCUMULATE 2u    /* bwd: add into grad_out AND loss_out instead of overwriting them (chunked batches) */
 #define PMG_FLAG_SKIP_WGRAD 4u    /* bwd, profiling aid: run the time recurrence only (grad_out untouched) */
 #define PMG_FLAG_ONLY_WGRAD 8u    /* bwd, profiling aid: redo the weight-gradient GEMM of the previous call */
+#define PMG_FLAG_REUSE_PACK 16u   /* logprob_fwd: `ws` still holds the packed weights of the previous
+                                     pmg_logprob_fwd call on it (same weights, same model dimensions; B and T
+                                     may differ): skip the packing kernels.  For batches run in chunks. */
 
 typedef void* pmg_stream; /* hipStream_t */
 
@@ -140,9 +143,13 @@ size_t pmg_noalloc_scratch_bytes(void);
  *   tokens   [T,B] int64 (pad_sequence layout)
  *   h0       [L,B,H] = latent_to_hidden(...) (reinforce_omics.py:313-317)
  *   logp_out [T-1,B]
- *   h_out    [L,B,H] final hidden, may be NULL */
+ *   h_out    [L,B,H] final hidden, may be NULL
+ *   flags    0 or PMG_FLAG_REUSE_PACK
+ * A batch too large for one workspace runs as chunks on one `ws`: per chunk pmg_logprob_fwd then
+ * pmg_reinforce_bwd, chunks after the first with PMG_FLAG_REUSE_PACK / PMG_FLAG_ACCUMULATE and the
+ * same `scale` (BASELINE.json configs[3]: B=16384, T=258 as 4 chunks of 4096). */
 int pmg_logprob_fwd(const pmg_shape* s, const pmg_weights* w, const int64_t* tokens,
-                    const float* h0, float* logp_out, float* h_out,
+                    const float* h0, float* logp_out, float* h_out, uint32_t flags,
                     void* ws, pmg_stream stream);
 
 /* Reward-weighted BPTT -- replaces rl_loss.backward() (reinforce_omics.py:335) for

@@ -18,7 +18,8 @@ PMG_FLAG_NO_EARLY_EXIT = 1
 PMG_FLAG_ACCUMULATE = 2
 PMG_FLAG_SKIP_WGRAD = 4
 PMG_FLAG_ONLY_WGRAD = 8
-PMG_ABI_VERSION = 1
+PMG_FLAG_REUSE_PACK = 16
+PMG_ABI_VERSION = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PMG_LIB selects a tuning variant built by __graft_entry__.build(extra_flags=..., libname=...)
@@ -78,7 +79,7 @@ def _load():
         C.c_uint64, C.c_uint64, C.c_int64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pmg_logprob_fwd.argtypes = [
         C.POINTER(PmgShape), C.POINTER(PmgWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-        C.c_void_p, C.c_void_p]
+        C.c_uint32, C.c_void_p, C.c_void_p]
     lib.pmg_reinforce_bwd.argtypes = [
         C.POINTER(PmgShape), C.POINTER(PmgWeights), C.c_void_p, C.c_void_p, C.c_float, C.c_uint32,
         C.POINTER(PmgGrads), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -284,7 +284,7 @@ static void fill_history(FwdArgs* a, const PmgDims& d, const PmgLayout& lay, flo
 }
 
 extern "C" int pmg_logprob_fwd(const pmg_shape* s, const pmg_weights* w, const int64_t* tokens, const float* h0,
-                               float* logp_out, float* h_out, void* ws, pmg_stream stream) {
+                               float* logp_out, float* h_out, uint32_t flags, void* ws, pmg_stream stream) {
   int rc = pmg_check_shape(s, PMG_MODE_TRAIN);
   if (rc) return rc;
   if (!tokens || !h0 || !logp_out || !ws) return PMG_E_NULL;
@@ -294,7 +294,10 @@ extern "C" int pmg_logprob_fwd(const pmg_shape* s, const pmg_weights* w, const i
   PmgLayout lay;
   make_layout(d, PMG_MODE_TRAIN, &lay);
   float* base = ws_base(ws);
-  if ((rc = pack_weights(d, lay, base, w, PMG_MODE_TRAIN, false, st))) return rc;
+  // the packed-weight region sits at the start of the workspace and its layout depends only on the
+  // model dimensions, so a caller that runs a batch in chunks on one workspace packs once
+  if (!(flags & PMG_FLAG_REUSE_PACK))
+    if ((rc = pack_weights(d, lay, base, w, PMG_MODE_TRAIN, false, st))) return rc;
   FwdArgs a;
   fill_fwd_common(&a, d, lay, base);
   fill_history(&a, d, lay, base);

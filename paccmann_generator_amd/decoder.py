@@ -128,6 +128,10 @@ class Generator(nn.Module):
         stop = int(torch.as_tensor(end_token).reshape(-1)[0])
         dev = self.decoder.output_layer.weight.device
         latent = latent_z.to(dev)
+        if latent.shape[-2] == 0:      # empty shard of a data-parallel batch: nothing to decode
+            self.skip_draws(generate_len)
+            return (torch.zeros(0, int(generate_len), dtype=torch.int64, device=dev),
+                    torch.zeros(0, dtype=torch.int32, device=dev))
         tokens, lens = ops.decode(self.decoder.weights(), latent, start, stop, int(generate_len),
                                   temperature=float(temperature), seed=self._philox_seed,
                                   offset=self._philox_offset, seq_index_base=seq_index_base,
@@ -135,10 +139,17 @@ class Generator(nn.Module):
         self._philox_offset += int(generate_len)
         return tokens, lens
 
-    def generate(self, latent_z, prime_input, end_token, generate_len=100, search=None):
+    def skip_draws(self, generate_len: int) -> None:
+        """Advance the Philox offset as one generate call would (a data-parallel rank with an empty
+        shard stays in step with the others)."""
+        self._philox_offset += int(generate_len)
+
+    def generate(self, latent_z, prime_input, end_token, generate_len=100, search=None, seq_index_base: int = 0):
         """Same call and result as at reinforce.py:162-170: an iterable of 1-D token
-        tensors, start token stripped, cut before the first end token."""
-        tokens, lens = self.generate_tokens(latent_z, prime_input, end_token, generate_len, search)
+        tensors, start token stripped, cut before the first end token.  ``seq_index_base`` (not in
+        the reference): global index of the first row when the batch is a shard of a larger one."""
+        tokens, lens = self.generate_tokens(latent_z, prime_input, end_token, generate_len, search,
+                                            seq_index_base=seq_index_base)
         return _CroppedRows(tokens.cpu(), lens.cpu())
 
     # -- checkpoints: plain state_dict .pt (format unchanged) ---------------------

@@ -1,39 +1,50 @@
-"""Operators over the C ABI: sampling decode, teacher-forced log-probs, REINFORCE loss.
+"""Operators over the C ABI, registered with ``torch.library`` under the namespace ``pmg``.
 
-These are the three pieces of the reference loop that move to the GPU:
-``generator.generate`` (reinforce.py:162-170), the teacher-forced loop
-(reinforce_omics.py:319-332) and ``rl_loss.backward()`` (:335).
+These are the pieces of the reference loop that move to the GPU: ``generator.generate``
+(reinforce.py:162-170), the teacher-forced loop (reinforce_omics.py:319-332),
+``rl_loss.backward()`` (:335), the single decoder step of the protocol (:323-325) and the
+per-molecule detokenisation (reinforce.py:172-176).
+
+    torch.ops.pmg.decode          -> pmg_decode
+    torch.ops.pmg.step            -> pmg_step
+    torch.ops.pmg.logprob_fwd     -> pmg_logprob_fwd          (returns the history workspace)
+    torch.ops.pmg.reinforce_bwd   -> pmg_reinforce_bwd        (consumes that workspace)
+    torch.ops.pmg.reinforce_loss  -> both, chunked over the batch; the differentiable operator
+    torch.ops.pmg.detokenize      -> pmg_detokenize
+
+Every operator has a schema, a fake (meta) implementation and only a CUDA implementation: there is
+no CPU path.  Decoder parameters travel as one ``Tensor[]`` in the order of
+``DecoderWeights.NAMES`` (per-layer entries expanded): 4 L + 7 tensors; all model dimensions except
+the stack depth are read off their shapes.  Workspaces are private to a call (torch's caching
+allocator makes that cheap), so calls on different streams or threads never share scratch.
 """
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
+from torch import Tensor
 
 from . import _ffi
 
-_WS: Dict[tuple, torch.Tensor] = {}
-
-
-def _workspace(shape, mode: int, device, private: bool = False) -> torch.Tensor:
-    need = _ffi.workspace_bytes(shape, mode)
-    if private:
-        return torch.empty(need, dtype=torch.uint8, device=device)
-    key = (str(device), mode)
-    ws = _WS.get(key)
-    if ws is None or ws.numel() < need:
-        ws = None
-        _WS.pop(key, None)
-        ws = torch.empty(need, dtype=torch.uint8, device=device)
-        _WS[key] = ws
-    return ws
+# Largest workspace one kernel call of the training pair may take; larger batches run as chunks whose
+# gradients accumulate (PMG_FLAG_ACCUMULATE).  96 GiB of the 288 GB of HBM: configs[3] (2 layers,
+# hidden 1024, T=258) needs ~20 GB per 1024 sequences, so B=16384 runs as 4 chunks of 4096.
+WORKSPACE_BUDGET_BYTES = 96 << 30
 
 
 def release_workspaces() -> None:
-    _WS.clear()
+    """Kept for callers of the r01 interface: workspaces are per call now; this only returns
+    torch's cached blocks to the driver."""
+    torch.cuda.empty_cache()
 
 
+def _alloc_ws(shape, mode: int, device) -> Tensor:
+    return torch.empty(_ffi.workspace_bytes(shape, mode), dtype=torch.uint8, device=device)
+
+
+# --------------------------------------------------------------------------------- parameters
 class DecoderWeights:
     """Views of a decoder's parameters in the order/naming of ``pmg_weights``."""
 
@@ -61,8 +72,13 @@ class DecoderWeights:
             pad_idx=decoder.embedding.padding_idx,
         )
 
-    def flat(self) -> List[torch.Tensor]:
-        """Parameters in the fixed order used by ReinforceLossFn (latent_to_hidden excluded)."""
+    @property
+    def pad_idx(self) -> int:
+        p = self.dims['pad_idx']
+        return -1 if p is None else int(p)
+
+    def flat(self) -> List[Tensor]:
+        """Parameters in the fixed order of the operators' ``params`` list (latent_to_hidden excluded)."""
         out = []
         for n in self.NAMES:
             v = self.t[n]
@@ -70,7 +86,7 @@ class DecoderWeights:
         return out
 
     @staticmethod
-    def unflatten(flat: List[torch.Tensor], L: int) -> dict:
+    def unflatten(flat: Sequence[Tensor], L: int) -> dict:
         it = iter(flat)
         d = {}
         for n in DecoderWeights.NAMES:
@@ -92,20 +108,49 @@ class DecoderWeights:
         return _ffi.pack_weight_struct(_ffi.PmgWeights, t, self.n_layers)
 
 
-@torch.no_grad()
-def decode(weights: DecoderWeights, latent: torch.Tensor, start_tok: int, stop_tok: int, gen_len: int,
-           temperature: float = 1.0, seed: int = 0, offset: int = 0, seq_index_base: int = 0,
-           early_exit: bool = True):
-    """Returns (tokens [B,gen_len] int64, lengths [B] int32).  latent: [B,Z] or [1,B,Z]."""
-    if latent.dim() == 3:
-        latent = latent[0]
+def _dims_of(params: Sequence[Tensor], stack_depth: int, pad_idx: int, Z: int = 32) -> dict:
+    """Model dimensions from the shapes of the flat parameter list."""
+    n = len(params)
+    if n < 11 or (n - 7) % 4:
+        raise _ffi.PmgError(f'pmg: expected 4*L+7 decoder parameters, got {n}')
+    L = (n - 7) // 4
+    V, E = params[0].shape
+    H = params[1 + L].shape[1]                 # w_hh[0]: [3H, H]
+    W = params[1].shape[1] - E                 # w_ih[0]: [3H, E+W]
+    return dict(H=int(H), E=int(E), W=int(W), D=int(stack_depth), V=int(V), L=int(L), Z=int(Z), pad_idx=int(pad_idx))
+
+
+def _shape(d: dict, B: int, T: int):
+    return _ffi.make_shape(B, T, d['H'], d['E'], d['W'], d['D'], d['V'], d['L'], d['Z'], d['pad_idx'])
+
+
+def _wstruct(params: Sequence[Tensor], L: int, w_l2h: Optional[Tensor] = None, b_l2h: Optional[Tensor] = None):
+    t = DecoderWeights.unflatten([p.detach() for p in params], L)
+    if w_l2h is not None:
+        t['w_l2h'], t['b_l2h'] = w_l2h.detach(), b_l2h.detach()
+    return _ffi.pack_weight_struct(_ffi.PmgWeights, t, L)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _ffi.PmgError('pmg: tensors must live on the GPU (there is no CPU path)')
+
+
+# --------------------------------------------------------------------------------- pmg::decode
+@torch.library.custom_op('pmg::decode', mutates_args=())
+def _decode_op(latent: Tensor, params: Sequence[Tensor], w_l2h: Tensor, b_l2h: Tensor, stack_depth: int,
+               pad_idx: int, start_tok: int, stop_tok: int, gen_len: int, temperature: float, seed: int,
+               offset: int, seq_index_base: int, early_exit: bool) -> Tuple[Tensor, Tensor]:
+    _need_cuda(latent, *params)
     latent = latent.detach().to(torch.float32).contiguous()
     B = latent.shape[0]
-    shape = weights.shape(B, gen_len)
-    ws = _workspace(shape, _ffi.PMG_MODE_DECODE, latent.device)
+    d = _dims_of(params, stack_depth, pad_idx, Z=latent.shape[1])
+    shape = _shape(d, B, gen_len)
+    ws = _alloc_ws(shape, _ffi.PMG_MODE_DECODE, latent.device)
     tokens = torch.empty(B, gen_len, dtype=torch.int64, device=latent.device)
     lens = torch.empty(B, dtype=torch.int32, device=latent.device)
-    wstruct, keep = weights.struct(True)
+    wstruct, keep = _wstruct(params, d['L'], w_l2h, b_l2h)
     flags = 0 if early_exit else _ffi.PMG_FLAG_NO_EARLY_EXIT
     rc = _ffi.lib.pmg_decode(C.byref(shape), C.byref(wstruct), _ffi._ptr(latent), int(start_tok), int(stop_tok),
                              int(gen_len), float(temperature), int(seed), int(offset), int(seq_index_base),
@@ -115,95 +160,299 @@ def decode(weights: DecoderWeights, latent: torch.Tensor, start_tok: int, stop_t
     return tokens, lens
 
 
+@_decode_op.register_fake
+def _(latent, params, w_l2h, b_l2h, stack_depth, pad_idx, start_tok, stop_tok, gen_len, temperature, seed, offset,
+      seq_index_base, early_exit):
+    B = latent.shape[0]
+    return latent.new_empty((B, gen_len), dtype=torch.int64), latent.new_empty((B,), dtype=torch.int32)
+
+
 @torch.no_grad()
-def step(weights: DecoderWeights, tok: torch.Tensor, hidden: torch.Tensor, stack: Optional[torch.Tensor],
-         want_logits: bool = True):
-    """One decoder step.  tok [B] or [1,B]; hidden [L,B,H]; stack [B,D,W] or None (zeros)."""
+def decode(weights: DecoderWeights, latent: Tensor, start_tok: int, stop_tok: int, gen_len: int,
+           temperature: float = 1.0, seed: int = 0, offset: int = 0, seq_index_base: int = 0,
+           early_exit: bool = True):
+    """Returns (tokens [B,gen_len] int64, lengths [B] int32).  latent: [B,Z] or [1,B,Z]."""
+    if latent.dim() == 3:
+        latent = latent[0]
+    return _decode_op(latent, weights.flat(), weights.t['w_l2h'], weights.t['b_l2h'], weights.dims['D'],
+                      weights.pad_idx, int(start_tok), int(stop_tok), int(gen_len), float(temperature), int(seed),
+                      int(offset), int(seq_index_base), bool(early_exit))
+
+
+# --------------------------------------------------------------------------------- pmg::step
+@torch.library.custom_op('pmg::step', mutates_args=())
+def _step_op(tok: Tensor, hidden: Tensor, stack: Optional[Tensor], params: Sequence[Tensor], stack_depth: int,
+             pad_idx: int, want_logits: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    _need_cuda(tok, hidden, stack, *params)
     tok = tok.reshape(-1).to(torch.int64).contiguous()
     hidden = hidden.detach().to(torch.float32).contiguous()
     B = tok.shape[0]
-    d = weights.dims
-    shape = weights.shape(B, 1)
-    ws = _workspace(shape, _ffi.PMG_MODE_DECODE, hidden.device)
+    d = _dims_of(params, stack_depth, pad_idx)
+    shape = _shape(d, B, 1)
+    ws = _alloc_ws(shape, _ffi.PMG_MODE_DECODE, hidden.device)
     h_out = torch.empty_like(hidden)
     s_out = torch.empty(B, d['D'], d['W'], dtype=torch.float32, device=hidden.device)
-    logits = torch.empty(B, d['V'], dtype=torch.float32, device=hidden.device) if want_logits else None
+    logits = torch.empty(B, d['V'] if want_logits else 0, dtype=torch.float32, device=hidden.device)
     s_in = None if stack is None else stack.detach().to(torch.float32).contiguous()
-    wstruct, keep = weights.struct(False)
+    wstruct, keep = _wstruct(params, d['L'])
     rc = _ffi.lib.pmg_step(C.byref(shape), C.byref(wstruct), _ffi._ptr(tok), _ffi._ptr(hidden), _ffi._ptr(s_in),
-                           _ffi._ptr(h_out), _ffi._ptr(s_out), _ffi._ptr(logits), _ffi._ptr(ws),
-                           _ffi.current_stream())
+                           _ffi._ptr(h_out), _ffi._ptr(s_out), _ffi._ptr(logits) if want_logits else None,
+                           _ffi._ptr(ws), _ffi.current_stream())
     _ffi.check(rc, 'pmg_step')
     del keep
     return h_out, s_out, logits
 
 
-class ReinforceLossFn(torch.autograd.Function):
-    """loss = -scale * sum_{p,b} reward[b] * logp[p,b]  (reinforce_omics.py:322-332 with
-    mean over the valid molecules = scale * sum), differentiable w.r.t. the decoder
-    parameters and h0.  Forward = pmg_logprob_fwd, backward = pmg_reinforce_bwd."""
-
-    @staticmethod
-    def forward(ctx, tokens, h0, reward, scale, dims, *params):
-        L = dims['L']
-        tokens = tokens.to(torch.int64).contiguous()
-        h0c = h0.detach().to(torch.float32).contiguous()
-        reward = reward.detach().to(torch.float32).reshape(-1).contiguous()
-        T, B = tokens.shape
-        shape = _ffi.make_shape(B, T, dims['H'], dims['E'], dims['W'], dims['D'], dims['V'], L, dims['Z'],
-                                dims['pad_idx'])
-        ws = _workspace(shape, _ffi.PMG_MODE_TRAIN, h0c.device, private=True)
-        wt = DecoderWeights.unflatten([p.detach() for p in params], L)
-        wstruct, keep = _ffi.pack_weight_struct(_ffi.PmgWeights, wt, L)
-        logp = torch.empty(T - 1, B, dtype=torch.float32, device=h0c.device)
-        rc = _ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(tokens), _ffi._ptr(h0c),
-                                      _ffi._ptr(logp), None, _ffi._ptr(ws), _ffi.current_stream())
-        _ffi.check(rc, 'pmg_logprob_fwd')
-        ctx.shape = shape
-        ctx.ws = ws
-        ctx.L = L
-        ctx.scale = float(scale)
-        ctx.save_for_backward(tokens, reward, *[p.detach() for p in params])
-        ctx.mark_non_differentiable(logp)
-        loss = -(logp * reward.unsqueeze(0)).sum() * float(scale)
-        return loss, logp
-
-    @staticmethod
-    def backward(ctx, grad_loss, _grad_logp):
-        tokens, reward, *params = ctx.saved_tensors
-        L = ctx.L
-        wt = DecoderWeights.unflatten(list(params), L)
-        wstruct, keep = _ffi.pack_weight_struct(_ffi.PmgWeights, wt, L)
-        grads = [torch.empty_like(p) for p in params]
-        gt = DecoderWeights.unflatten(grads, L)
-        gstruct, keep2 = _ffi.pack_weight_struct(_ffi.PmgGrads, gt, L)
-        shape = ctx.shape
-        grad_h0 = torch.empty(L, shape.B, shape.H, dtype=torch.float32, device=tokens.device)
-        loss = torch.empty(1, dtype=torch.float32, device=tokens.device)
-        rc = _ffi.lib.pmg_reinforce_bwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(tokens), _ffi._ptr(reward),
-                                        ctx.scale, 0, C.byref(gstruct), _ffi._ptr(grad_h0), _ffi._ptr(loss),
-                                        _ffi._ptr(ctx.ws), _ffi.current_stream())
-        _ffi.check(rc, 'pmg_reinforce_bwd')
-        ctx.ws = None
-        ctx.bwd_loss = loss
-        gl = grad_loss.to(torch.float32)
-        grads = [g * gl for g in grads]
-        return (None, grad_h0 * gl, None, None, None, *grads)
-
-
-def reinforce_loss(weights: DecoderWeights, tokens: torch.Tensor, h0: torch.Tensor, reward: torch.Tensor,
-                   scale: float):
-    """Returns (loss, logp[T-1,B]).  tokens [T,B] (pad_sequence layout), h0 [L,B,H], reward [B]."""
-    return ReinforceLossFn.apply(tokens, h0, reward, scale, weights.dims, *weights.flat())
+@_step_op.register_fake
+def _(tok, hidden, stack, params, stack_depth, pad_idx, want_logits):
+    B = tok.numel()
+    V, E = params[0].shape
+    W = params[1].shape[1] - E
+    return (torch.empty_like(hidden), hidden.new_empty((B, stack_depth, W)),
+            hidden.new_empty((B, V if want_logits else 0)))
 
 
 @torch.no_grad()
-def teacher_forced_logprobs(weights: DecoderWeights, tokens: torch.Tensor, h0: torch.Tensor) -> torch.Tensor:
-    """logp [T-1,B] without keeping a graph."""
+def step(weights: DecoderWeights, tok: Tensor, hidden: Tensor, stack: Optional[Tensor],
+         want_logits: bool = True):
+    """One decoder step.  tok [B] or [1,B]; hidden [L,B,H]; stack [B,D,W] or None (zeros)."""
+    h_out, s_out, logits = _step_op(tok, hidden, stack, weights.flat(), weights.dims['D'], weights.pad_idx,
+                                    bool(want_logits))
+    return h_out, s_out, (logits if want_logits else None)
+
+
+# --------------------------------------------------------------------------------- training pair
+def _check_train_inputs(tokens: Tensor, h0: Tensor, d: dict):
+    _need_cuda(tokens, h0)
+    if tokens.dim() != 2 or h0.dim() != 3:
+        raise _ffi.PmgError('pmg: tokens must be [T,B] and h0 [L,B,H]')
     T, B = tokens.shape
+    if h0.shape != (d['L'], B, d['H']):
+        raise _ffi.PmgError(f'pmg: h0 must be [{d["L"]},{B},{d["H"]}], got {tuple(h0.shape)}')
+    return T, B
+
+
+def _fwd_call(shape, wstruct, tokens, h0, logp, ws, flags=0):
+    rc = _ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(tokens), _ffi._ptr(h0),
+                                   _ffi._ptr(logp), None, flags, _ffi._ptr(ws), _ffi.current_stream())
+    _ffi.check(rc, 'pmg_logprob_fwd')
+
+
+@torch.library.custom_op('pmg::logprob_fwd', mutates_args=())
+def _logprob_fwd_op(tokens: Tensor, h0: Tensor, params: Sequence[Tensor], stack_depth: int,
+                    pad_idx: int) -> Tuple[Tensor, Tensor]:
+    """(logp [T-1,B], ws): ``ws`` holds the trajectory pmg::reinforce_bwd differentiates."""
+    d = _dims_of(params, stack_depth, pad_idx)
+    T, B = _check_train_inputs(tokens, h0, d)
+    tokens = tokens.to(torch.int64).contiguous()
+    h0c = h0.detach().to(torch.float32).contiguous()
+    shape = _shape(d, B, T)
+    # returned to the caller, so zero-filled: the operator stays a pure function of its inputs (the
+    # regions the backward will write, and alignment gaps, would otherwise hold stale memory)
+    ws = torch.zeros(_ffi.workspace_bytes(shape, _ffi.PMG_MODE_TRAIN), dtype=torch.uint8, device=h0c.device)
+    wstruct, keep = _wstruct(params, d['L'])
+    logp = torch.empty(T - 1, B, dtype=torch.float32, device=h0c.device)
+    _fwd_call(shape, wstruct, tokens, h0c, logp, ws)
+    del keep
+    return logp, ws
+
+
+@_logprob_fwd_op.register_fake
+def _(tokens, h0, params, stack_depth, pad_idx):
+    T, B = tokens.shape
+    d = _dims_of(params, stack_depth, pad_idx)
+    need = _ffi.workspace_bytes(_shape(d, int(B), int(T)), _ffi.PMG_MODE_TRAIN)   # host-only size query
+    return h0.new_empty((T - 1, B)), h0.new_empty((need,), dtype=torch.uint8)
+
+
+def _grad_struct(grads: Sequence[Tensor], L: int):
+    return _ffi.pack_weight_struct(_ffi.PmgGrads, DecoderWeights.unflatten(list(grads), L), L)
+
+
+@torch.library.custom_op('pmg::reinforce_bwd', mutates_args=('ws',))   # scratch regions of ws are written
+def _reinforce_bwd_op(tokens: Tensor, reward: Tensor, scale: float, ws: Tensor, params: Sequence[Tensor],
+                      stack_depth: int, pad_idx: int) -> Tuple[Tensor, Tensor, List[Tensor]]:
+    """(loss [1], grad_h0 [L,B,H], one gradient per parameter) from the trajectory in ``ws``."""
+    _need_cuda(tokens, reward, ws)
+    d = _dims_of(params, stack_depth, pad_idx)
+    T, B = tokens.shape
+    tokens = tokens.to(torch.int64).contiguous()
+    reward = reward.detach().to(torch.float32).reshape(-1).contiguous()
+    shape = _shape(d, B, T)
+    if ws.numel() < _ffi.workspace_bytes(shape, _ffi.PMG_MODE_TRAIN):
+        raise _ffi.PmgError('pmg::reinforce_bwd: workspace does not belong to this shape')
+    wstruct, keep = _wstruct(params, d['L'])
+    grads = [torch.empty_like(p, dtype=torch.float32) for p in params]
+    gstruct, keep2 = _grad_struct(grads, d['L'])
+    grad_h0 = torch.empty(d['L'], B, d['H'], dtype=torch.float32, device=tokens.device)
+    loss = torch.empty(1, dtype=torch.float32, device=tokens.device)
+    rc = _ffi.lib.pmg_reinforce_bwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(tokens), _ffi._ptr(reward),
+                                    float(scale), 0, C.byref(gstruct), _ffi._ptr(grad_h0), _ffi._ptr(loss),
+                                    _ffi._ptr(ws), _ffi.current_stream())
+    _ffi.check(rc, 'pmg_reinforce_bwd')
+    del keep, keep2
+    return loss, grad_h0, grads
+
+
+@_reinforce_bwd_op.register_fake
+def _(tokens, reward, scale, ws, params, stack_depth, pad_idx):
+    T, B = tokens.shape
+    L = (len(params) - 7) // 4
+    H = params[1 + L].shape[1]
+    return (reward.new_empty((1,), dtype=torch.float32), reward.new_empty((L, B, H), dtype=torch.float32),
+            [torch.empty_like(p) for p in params])
+
+
+def plan_chunks(d: dict, B: int, T: int, budget: Optional[int] = None, chunk: int = 0) -> List[Tuple[int, int]]:
+    """[lo, hi) slices of the batch, each a whole number of 16-sequence row groups (but the last),
+    whose training workspace fits ``budget`` bytes.  ``chunk`` > 0 fixes the slice size instead."""
+    if chunk <= 0:
+        budget = WORKSPACE_BUDGET_BYTES if budget is None else int(budget)
+        per16 = _ffi.workspace_bytes(_shape(d, 32, T), _ffi.PMG_MODE_TRAIN) - \
+            _ffi.workspace_bytes(_shape(d, 16, T), _ffi.PMG_MODE_TRAIN)
+        fixed = _ffi.workspace_bytes(_shape(d, 16, T), _ffi.PMG_MODE_TRAIN) - per16
+        groups = max(1, int((budget - fixed) // max(1, per16)))
+        chunk = groups * 16
+        if chunk < B:    # balance: same number of chunks, equal sizes
+            n = -(-B // chunk)
+            chunk = -(-(-(-B // n)) // 16) * 16
+    else:
+        chunk = -(-int(chunk) // 16) * 16
+    return [(lo, min(B, lo + chunk)) for lo in range(0, B, chunk)]
+
+
+@torch.library.custom_op('pmg::reinforce_loss', mutates_args=())
+def _reinforce_loss_op(tokens: Tensor, h0: Tensor, reward: Tensor, scale: float, params: Sequence[Tensor],
+                       stack_depth: int, pad_idx: int, chunk: int, with_grads: bool
+                       ) -> Tuple[Tensor, Tensor, Tensor, List[Tensor]]:
+    """loss = -scale * sum_{p,b} reward[b] * logp[p,b]  (reinforce_omics.py:322-332 with the mean over
+    the valid molecules written as scale * sum), its log-probs, and -- with ``with_grads`` -- the
+    gradient of the loss w.r.t. h0 and every parameter, formed in the same pass: per chunk of the
+    batch pmg_logprob_fwd then pmg_reinforce_bwd on one shared workspace, chunks after the first with
+    PMG_FLAG_ACCUMULATE.  Returns (loss [], logp [T-1,B], grad_h0 [L,B,H], grads)."""
+    d = _dims_of(params, stack_depth, pad_idx)
+    T, B = _check_train_inputs(tokens, h0, d)
+    _need_cuda(reward, *params)
+    dev = h0.device
+    tokens = tokens.to(torch.int64).contiguous()
+    h0c = h0.detach().to(torch.float32).contiguous()
+    reward = reward.detach().to(torch.float32).reshape(-1).contiguous()
+    if reward.numel() != B:
+        raise _ffi.PmgError('pmg: one reward per sequence required')
+    L, H = d['L'], d['H']
+    chunks = plan_chunks(d, B, T, chunk=chunk)
+    wstruct, keep = _wstruct(params, L)
+    logp = torch.empty(T - 1, B, dtype=torch.float32, device=dev)
+    if with_grads:
+        grads = [torch.empty_like(p, dtype=torch.float32) for p in params]
+        gstruct, keep2 = _grad_struct(grads, L)
+        grad_h0 = torch.empty(L, B, H, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+    else:
+        grads, grad_h0 = [], torch.empty(0, dtype=torch.float32, device=dev)
+    ws = _alloc_ws(_shape(d, chunks[0][1] - chunks[0][0], T), _ffi.PMG_MODE_TRAIN, dev)
+    st = _ffi.current_stream()
+    for i, (lo, hi) in enumerate(chunks):
+        whole = len(chunks) == 1
+        shape = _shape(d, hi - lo, T)
+        tok_c = tokens if whole else tokens[:, lo:hi].contiguous()
+        h0_c = h0c if whole else h0c[:, lo:hi].contiguous()
+        lp_c = logp if whole else torch.empty(T - 1, hi - lo, dtype=torch.float32, device=dev)
+        # the packed weights of chunk 0 are still in the workspace for the later chunks
+        _fwd_call(shape, wstruct, tok_c, h0_c, lp_c, ws, _ffi.PMG_FLAG_REUSE_PACK if i > 0 else 0)
+        if not whole:
+            logp[:, lo:hi] = lp_c
+        if with_grads:
+            r_c = reward if whole else reward[lo:hi].contiguous()
+            gh_c = grad_h0 if whole else torch.empty(L, hi - lo, H, dtype=torch.float32, device=dev)
+            rc = _ffi.lib.pmg_reinforce_bwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(tok_c), _ffi._ptr(r_c),
+                                            float(scale), _ffi.PMG_FLAG_ACCUMULATE if i > 0 else 0,
+                                            C.byref(gstruct), _ffi._ptr(gh_c), _ffi._ptr(loss), _ffi._ptr(ws), st)
+            _ffi.check(rc, 'pmg_reinforce_bwd')
+            if not whole:
+                grad_h0[:, lo:hi] = gh_c
+    if not with_grads:
+        loss = -(logp * reward.unsqueeze(0)).sum().reshape(1) * float(scale)
+    del keep
+    return loss.reshape(()), logp, grad_h0, grads
+
+
+@_reinforce_loss_op.register_fake
+def _(tokens, h0, reward, scale, params, stack_depth, pad_idx, chunk, with_grads):
+    T, B = tokens.shape
+    f32 = dict(dtype=torch.float32)
+    if with_grads:
+        return (h0.new_empty((), **f32), h0.new_empty((T - 1, B), **f32), h0.new_empty(h0.shape, **f32),
+                [torch.empty_like(p) for p in params])
+    return h0.new_empty((), **f32), h0.new_empty((T - 1, B), **f32), h0.new_empty((0,), **f32), []
+
+
+def _reinforce_setup(ctx, inputs, output):
+    tokens, h0, reward, scale, params, stack_depth, pad_idx, chunk, with_grads = inputs
+    _, _, grad_h0, grads = output
+    ctx.with_grads = bool(with_grads)
+    ctx.n_params = len(params)
+    ctx.h0_dtype = h0.dtype
+    ctx.save_for_backward(grad_h0, *grads)
+
+
+def _reinforce_backward(ctx, g_loss, g_logp, g_gh0, g_grads):
+    """The gradients were formed in the forward pass (for d loss = 1): scale them by the incoming
+    gradient of the scalar loss.  logp, grad_h0 and grads are results, not differentiable outputs."""
+    if not ctx.with_grads:
+        raise RuntimeError('pmg::reinforce_loss was called with with_grads=False: no gradient was formed')
+    grad_h0, *grads = ctx.saved_tensors
+    gl = g_loss.to(torch.float32)
+    return (None, (grad_h0 * gl).to(ctx.h0_dtype), None, None, [g * gl for g in grads], None, None, None, None)
+
+
+_reinforce_loss_op.register_autograd(_reinforce_backward, setup_context=_reinforce_setup)
+
+
+def check_token_range(tokens: Tensor, V: int) -> None:
+    """Host-side validation of token ids (one device->host round trip): the kernels only clamp."""
+    if tokens.numel() == 0:
+        return
+    lo, hi = int(tokens.min()), int(tokens.max())
+    if lo < 0 or hi >= V:
+        raise _ffi.PmgError(f'pmg: token ids must lie in [0, {V}), got [{lo}, {hi}]')
+
+
+def reinforce_loss(weights: DecoderWeights, tokens: Tensor, h0: Tensor, reward: Tensor, scale: float,
+                   chunk: int = 0, trusted_tokens: bool = False):
+    """Returns (loss, logp[T-1,B]).  tokens [T,B] (pad_sequence layout), h0 [L,B,H], reward [B].
+
+    Differentiable w.r.t. h0 and the decoder parameters.  ``chunk`` > 0 fixes the number of sequences
+    per kernel call; 0 lets the workspace budget decide.  ``trusted_tokens`` skips the id range check
+    (for rows cut from pmg_decode's own output)."""
+    if not trusted_tokens:
+        check_token_range(tokens, weights.dims['V'])
+    params = weights.flat()
+    with_grads = torch.is_grad_enabled() and (h0.requires_grad or any(p.requires_grad for p in params))
+    loss, logp, _, _ = _reinforce_loss_op(tokens, h0, reward, float(scale), params, weights.dims['D'],
+                                          weights.pad_idx, int(chunk), bool(with_grads))
+    return loss, logp.detach()      # the log-probs are a result, not a differentiable output
+
+
+@torch.no_grad()
+def teacher_forced_logprobs(weights: DecoderWeights, tokens: Tensor, h0: Tensor, chunk: int = 0) -> Tensor:
+    """logp [T-1,B] without forming gradients."""
+    B = tokens.shape[1]
     reward = torch.zeros(B, dtype=torch.float32, device=h0.device)
-    _, logp = ReinforceLossFn.apply(tokens, h0, reward, 1.0, weights.dims, *[p.detach() for p in weights.flat()])
+    _, logp = reinforce_loss(weights, tokens, h0, reward, 1.0, chunk=chunk)
     return logp
+
+
+# --------------------------------------------------------------------------------- pmg::detokenize
+@torch.library.custom_op('pmg::detokenize', mutates_args=('out_off', 'out_bytes'))
+def _detokenize_op(tokens: Tensor, lens: Tensor, tab_off: Tensor, tab_bytes: Tensor, max_tok_bytes: int,
+                   out_off: Tensor, out_bytes: Tensor) -> None:
+    _need_cuda(tokens, lens, tab_off, tab_bytes, out_off, out_bytes)
+    B, N = tokens.shape
+    rc = _ffi.lib.pmg_detokenize(_ffi._ptr(tokens), N, _ffi._ptr(lens), B, N, _ffi._ptr(tab_off),
+                                 _ffi._ptr(tab_bytes), tab_off.numel() - 1, int(max_tok_bytes), _ffi._ptr(out_off),
+                                 _ffi._ptr(out_bytes), out_bytes.numel(), _ffi.current_stream())
+    _ffi.check(rc, 'pmg_detokenize')
 
 
 class TokenTable:
@@ -243,7 +492,7 @@ class TokenTable:
 
 
 @torch.no_grad()
-def detokenize_device(table: TokenTable, tokens: torch.Tensor, lens: torch.Tensor):
+def detokenize_device(table: TokenTable, tokens: Tensor, lens: Tensor):
     """Stream-ordered, no synchronisation: (out_off [B+1] int64, out_bytes uint8) on the device;
     row b is out_bytes[out_off[b]:out_off[b+1]].  The buffers belong to ``table`` and are reused by
     the next call with the same (B, max_len)."""
@@ -255,14 +504,11 @@ def detokenize_device(table: TokenTable, tokens: torch.Tensor, lens: torch.Tenso
     if lens.numel() != B:
         raise _ffi.PmgError('pmg_detokenize: one length per row required')
     out_off, out_bytes = table.buffers(B, N)
-    rc = _ffi.lib.pmg_detokenize(_ffi._ptr(tokens), N, _ffi._ptr(lens), B, N, _ffi._ptr(table.tab_off),
-                                 _ffi._ptr(table.tab_bytes), table.V, table.max_tok_bytes, _ffi._ptr(out_off),
-                                 _ffi._ptr(out_bytes), out_bytes.numel(), _ffi.current_stream())
-    _ffi.check(rc, 'pmg_detokenize')
+    _detokenize_op(tokens, lens, table.tab_off, table.tab_bytes, table.max_tok_bytes, out_off, out_bytes)
     return out_off, out_bytes
 
 
-def detokenize(table: TokenTable, tokens: torch.Tensor, lens: torch.Tensor) -> List[str]:
+def detokenize(table: TokenTable, tokens: Tensor, lens: Tensor) -> List[str]:
     """Batched twin of ``[lang.token_indexes_to_smiles(row[:n].tolist()) for row, n in ...]``
     (reinforce.py:172-176): one device pass, two device->host copies, B string slices."""
     if tokens.shape[0] == 0:

@@ -112,8 +112,27 @@ class Reinforce(object):
             latent = latent.repeat(1, 1, 2)
         return latent
 
-    def sample_tokens(self, latent, seq_index_base: int = 0, early_exit: bool = True):
+    # ------------------------------------------------------------------ data-parallel sharding
+    def _dp_rank_world(self):
+        if self.process_group is None:
+            return 0, 1
+        import torch.distributed as dist
+        return dist.get_rank(self.process_group), dist.get_world_size(self.process_group)
+
+    def _local_batch(self, batch_size: int) -> int:
+        """Sequences of a GLOBAL batch of ``batch_size`` this rank decodes: the
+        contiguous slice dp.shard_range gives it.  Its first global index becomes the Philox
+        ``seq_index_base`` of the next decode, so N ranks sample exactly the rows a single process
+        would have sampled.  Without a process group: the whole batch."""
+        rank, world = self._dp_rank_world()
+        lo, hi = dp.shard_range(batch_size, rank, world)
+        self._seq_base = lo
+        return hi - lo
+
+    def sample_tokens(self, latent, seq_index_base: Optional[int] = None, early_exit: bool = True):
         """Device-side half of get_smiles_from_latent: (tokens [B,generate_len], lengths [B])."""
+        if seq_index_base is None:
+            seq_index_base = getattr(self, '_seq_base', 0)
         lang = self.generator.smiles_language
         return self.generator.generate_tokens(
             self._decoder_latent(latent),
@@ -161,6 +180,7 @@ class Reinforce(object):
                 end_token=torch.Tensor([lang.stop_index]).long(),
                 generate_len=self.generate_len,
                 search=SamplingSearch(temperature=self.temperature),
+                seq_index_base=getattr(self, '_seq_base', 0),
             )
             stops = torch.tensor(2 * [lang.stop_index])
             rows = list(iter(mols_numerical))
@@ -180,59 +200,78 @@ class Reinforce(object):
         return [smiles[i] for i in keep], [numericals[i] for i in keep], valid_idxs
 
     # ------------------------------------------------------------------ learning
-    def _all_reduce_gradients(self, extra_params=()):
-        """One RCCL all-reduce (sum) of the flat gradient buffer."""
-        dp.all_reduce_gradients_(list(self.generator.decoder.parameters()) + list(extra_params),
-                                 group=self.process_group)
-
-    def _global_count(self, n: int) -> int:
-        if self.process_group is None:
-            return n
-        return int(round(dp.global_sum(n, self.device, self.process_group)))
-
-    def learn(self, latent_z, padded_nums, valid_idx, rewards, lrps: int = 1, n_valid_global=None):
+    def learn(self, latent_z, padded_nums, valid_idx, rewards, lrps: int = 1):
         """reinforce_omics.py:301-342 given sampled + scored molecules.
 
         latent_z [1,B,latent_size] (autograd-connected to the encoder), padded_nums
         [T_max,B_valid] (pad_sequence layout), valid_idx indices into B, rewards [B_valid].
-        Returns (mean_reward, loss_float)."""
+        Returns (mean_reward, loss) as 0-dim tensors.
+
+        With a process group these are this rank's shard and the step is data parallel: the kernel
+        forms gradient SUMS (scale 1), ONE all-reduce carries [gradients | loss sum | reward sum |
+        valid count] (dp.reduce_step_), everything is divided by the global valid count afterwards,
+        and clip + Adam run replicated.  Every rank takes part in that collective, also a rank with
+        no valid molecule (it contributes zeros); the update is skipped only when no rank has one."""
         dec = self.generator.decoder
         dev = self.device
-        self.optimizer.zero_grad()
         rewards_t = torch.as_tensor(np.asarray(rewards), dtype=torch.float32) if not torch.is_tensor(rewards) \
             else rewards.to(torch.float32)
-        num_mols = padded_nums.shape[1]
-        dec._update_batch_size(num_mols)
-        idx = valid_idx if torch.is_tensor(valid_idx) else torch.as_tensor(valid_idx, dtype=torch.long)
-        hidden = dec.latent_to_hidden(
-            latent_z.to(dev).repeat(dec.n_layers, 1, lrps)[:, idx.to(dev), :])
-        n_glob = n_valid_global if n_valid_global is not None else self._global_count(num_mols)
-        loss, _ = ops.reinforce_loss(dec.weights(), padded_nums.to(dev), hidden, rewards_t.to(dev),
-                                     1.0 / max(1, n_glob))
-        summed_reward = torch.mean(rewards_t.float())
-        loss.backward()
+        rewards_t = rewards_t.reshape(-1)
+        num_mols = padded_nums.shape[1] if padded_nums.dim() == 2 else 0
+        ddp = self.process_group is not None
         enc_params = list(self.encoder.parameters()) if self.encoder is not None else []
-        if self.process_group is not None:
-            self._all_reduce_gradients(enc_params)
+        dec_params = list(dec.parameters())
+        if not ddp and num_mols == 0:
+            return torch.tensor(0.0), torch.tensor(0.0)
+
+        def run(scale):
+            dec._update_batch_size(num_mols)
+            idx = valid_idx if torch.is_tensor(valid_idx) else torch.as_tensor(valid_idx, dtype=torch.long)
+            hidden = dec.latent_to_hidden(
+                latent_z.to(dev).repeat(dec.n_layers, 1, lrps)[:, idx.to(dev), :])
+            loss, _ = ops.reinforce_loss(dec.weights(), padded_nums.to(dev), hidden, rewards_t.to(dev), scale,
+                                         trusted_tokens=self._tokens_trusted)
+            loss.backward()
+            return loss.detach()
+
+        if ddp:
+            r, l, _ = dp.data_parallel_step(dec_params, enc_params, self.optimizer, lambda: run(1.0), num_mols,
+                                            float(rewards_t.sum()) if num_mols > 0 else 0.0, self.grad_clipping,
+                                            group=self.process_group)
+            return torch.tensor(r), torch.tensor(l)
+        self.optimizer.zero_grad()
+        loss = run(1.0 / num_mols)
+        summed_reward = torch.mean(rewards_t.float())
         if self.grad_clipping is not None:
-            torch.nn.utils.clip_grad_norm_(list(dec.parameters()) + enc_params, self.grad_clipping)
+            torch.nn.utils.clip_grad_norm_(dec_params + enc_params, self.grad_clipping)
         self.optimizer.step()
         return summed_reward, loss
 
+    _tokens_trusted = False   # set while the rows come from this object's own decode (ids in range by construction)
+
     def _policy_gradient(self, latent_z, target):
-        valid_smiles, valid_nums, valid_idx = self.get_smiles_from_latent(latent_z, remove_invalid=True)
+        B_local = latent_z.shape[1]
+        if B_local > 0:
+            valid_smiles, valid_nums, valid_idx = self.get_smiles_from_latent(latent_z, remove_invalid=True)
+        else:   # empty shard (global batch smaller than the world): keep the Philox offset in step
+            self.generator.skip_draws(self.generate_len)
+            valid_smiles, valid_nums, valid_idx = [], [], []
         if len(valid_nums) == 0:
             if self.logger is not None:
-                self.logger.warning('no valid molecule in the batch: update skipped')
-            return torch.tensor(0.0), 0.0
-        rewards = self.get_reward(valid_smiles, target)
-        padded_nums = self._padded_valid(valid_nums, valid_idx)
+                self.logger.warning('no valid molecule in the batch' +
+                                    (' of this rank' if self.process_group is not None else ': update skipped'))
+            if self.process_group is None:
+                return torch.tensor(0.0), 0.0
+            rewards, padded_nums = np.zeros(0, dtype=np.float32), torch.zeros(0, 0, dtype=torch.long)
+        else:
+            rewards = self.get_reward(valid_smiles, target)
+            padded_nums = self._padded_valid(valid_nums, valid_idx)
         lrps = 1
         if self.encoder is not None and \
                 self.generator.decoder.latent_dim == 2 * getattr(self.encoder, 'latent_size', -1):
             lrps = 2
         r, loss = self.learn(latent_z, padded_nums, valid_idx, rewards, lrps)
-        return r, loss.item()
+        return r, float(loss)
 
     def _padded_valid(self, valid_nums, valid_idx):
         """pad_sequence(valid_nums) (reinforce_omics.py:304).  When the rows are the ones the device
@@ -244,8 +283,10 @@ class Reinforce(object):
                 all(valid_nums[j] is last[2][i] for j, i in ((0, valid_idx[0]), (-1, valid_idx[-1]))):
             tokens, lens, _ = last
             idx = torch.as_tensor(valid_idx, dtype=torch.long, device=tokens.device)
+            self._tokens_trusted = True      # rows cut from pmg_decode's own output: ids are in range
             return pad_rows_on_device(tokens.index_select(0, idx), lens.index_select(0, idx),
                                       self.generator.smiles_language.stop_index)
+        self._tokens_trusted = False
         return torch.nn.utils.rnn.pad_sequence(valid_nums)
 
     def get_reward(self, valid_smiles, target):
@@ -257,6 +298,7 @@ class Reinforce(object):
         """Sampling-only entry shared by generate_compounds_and_evaluate of the subclasses
         (reinforce_omics.py:164-180, reinforce_proteins.py:180-198): decode, then score the valid
         molecules with the host-side ``score_fn`` (the predictor forward is out of scope)."""
+        self._seq_base = 0     # evaluation is not sharded: every rank decodes the whole batch
         valid_smiles, valid_nums, _ = self.get_smiles_from_latent(latent_z, remove_invalid=remove_invalid)
         score_fn = getattr(self, 'score_fn', None) or self.reward_fn
         if score_fn is None:
@@ -304,7 +346,7 @@ class ReinforceOmic(Reinforce):
 
     def policy_gradient(self, cell_line, epoch, batch_size=10):
         """reinforce_omics.py:276-342.  Returns (mean reward, loss float)."""
-        latent_z = self.encode_cell_line(cell_line, batch_size)
+        latent_z = self.encode_cell_line(cell_line, self._local_batch(batch_size))
         return self._policy_gradient(latent_z, cell_line)
 
     def generate_compounds_and_evaluate(self, epoch, batch_size, cell_line=None, primed_drug=' ',
@@ -344,7 +386,7 @@ class ReinforceProtein(Reinforce):
 
     def policy_gradient(self, protein, epoch, batch_size=10):
         """reinforce_proteins.py:267-331."""
-        latent_z = self.encode_protein(protein, batch_size)
+        latent_z = self.encode_protein(protein, self._local_batch(batch_size))
         return self._policy_gradient(latent_z, protein)
 
     def generate_compounds_and_evaluate(self, epoch, batch_size, protein=None, primed_drug=' ',
@@ -390,7 +432,7 @@ class ReinforceMultiModalSets(Reinforce):
 
     def policy_gradient(self, cell_line, protein, epoch, batch_size=10):
         """reinforce_sets.py:438-502."""
-        latent_z = self.encode_set(cell_line, protein, batch_size)
+        latent_z = self.encode_set(cell_line, protein, self._local_batch(batch_size))
         return self._policy_gradient(latent_z, (protein, cell_line))
 
 

@@ -54,6 +54,17 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
+def elem_err(a, b, floor=1e-2):
+    """Element-wise bar next to the max-norm one: the largest |a-b| / (|b| + floor*max|b|), i.e.
+    |a-b| <= tol*|b| + tol*floor*max|b| for every element (tol=1e-4, floor=1e-2: the absolute floor
+    is 1e-6 of the tensor's largest entry).  Returns (worst value, flat index of the worst element)."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    e = np.abs(a - b) / (np.abs(b) + floor * np.abs(b).max() + 1e-300)
+    i = int(e.argmax())
+    return float(e[i]), i
+
+
 def oracle_train(odec, tokens, h0, reward, scale, dtype=torch.float32):
     """Loss, logp and every gradient by torch autograd over the reference loop."""
     dec = odec if dtype == torch.float32 else _clone_as(odec, dtype)
@@ -78,21 +89,27 @@ def _clone_as(odec, dtype):
     return d.eval()
 
 
-def product_train(pdec, tokens, h0, reward, scale):
+def product_train(pdec, tokens, h0, reward, scale, chunk=0):
     from paccmann_generator_amd import ops
     dev = pdec.output_layer.weight.device
     for p in pdec.parameters():
         p.grad = None
     h0d = h0.to(dev).clone().requires_grad_(True)
-    loss, logp = ops.reinforce_loss(pdec.weights(), tokens.to(dev), h0d, reward.to(dev), scale)
+    loss, logp = ops.reinforce_loss(pdec.weights(), tokens.to(dev), h0d, reward.to(dev), scale, chunk=chunk)
     loss.backward()
     torch.cuda.synchronize()
     grads = {n: p.grad.detach().cpu().clone() for n, p in pdec.named_parameters() if p.grad is not None}
     return loss.item(), logp.cpu(), grads, h0d.grad.detach().cpu().clone()
 
 
-def check_train(params, B, T, seed=0, tol=1e-4, verbose=False):
-    """Teacher-forced log-probs + REINFORCE gradients, HIP vs oracle autograd (fp32 and fp64)."""
+def check_train(params, B, T, seed=0, tol=1e-4, verbose=False, chunk=0, elem_tol=1e-4):
+    """Teacher-forced log-probs + REINFORCE gradients, HIP vs oracle autograd in fp64.
+
+    Two bars per tensor: max-norm (max|a-b| / max|b| <= tol) and element-wise (elem_err <= elem_tol).
+    An element that misses the element-wise bar is accepted only if the fp32 CPU oracle -- the same
+    arithmetic in the same precision, another summation order -- is itself at least a third as far
+    from the fp64 oracle there: then the miss is fp32 summation noise on a small entry, not a defect.
+    Such entries are listed in report['noise']."""
     odec, pdec = make_pair(params, seed=seed)
     L, H = params['n_layers'], params['rnn_cell_size']
     tokens = synthetic_tokens(T, B, params['vocab_size'], seed=seed + 3)
@@ -102,20 +119,40 @@ def check_train(params, B, T, seed=0, tol=1e-4, verbose=False):
     reward = torch.rand(B)
     scale = 1.0 / B
     o_loss, o_logp, o_grads, o_gh0 = oracle_train(odec, tokens, h0, reward, scale, torch.float64)
-    p_loss, p_logp, p_grads, p_gh0 = product_train(pdec, tokens, h0, reward, scale)
-    report = {}
-    report['logp'] = rel_err(p_logp, o_logp)
-    report['loss'] = abs(p_loss - o_loss) / (abs(o_loss) + 1e-30)
-    report['grad_h0'] = rel_err(p_gh0, o_gh0)
+    p_loss, p_logp, p_grads, p_gh0 = product_train(pdec, tokens, h0, reward, scale, chunk=chunk)
+    pairs = {'logp': (p_logp, o_logp), 'grad_h0': (p_gh0, o_gh0)}
     for n, g in o_grads.items():
-        if n.startswith('latent_to_hidden'):
-            continue
-        report[n] = rel_err(p_grads[n], g)
+        if not n.startswith('latent_to_hidden'):
+            pairs[n] = (p_grads[n], g)
+    report = {'loss': abs(p_loss - o_loss) / (abs(o_loss) + 1e-30)}
+    elem = {}
+    for n, (a, b) in pairs.items():
+        report[n] = rel_err(a, b)
+        elem[n] = elem_err(a, b)
     if verbose:
         for k, v in report.items():
-            print(f'  {k:40s} {v:.3e}')
+            print(f'  {k:40s} {v:.3e}  elem {elem.get(k, (0, 0))[0]:.3e}')
     bad = {k: v for k, v in report.items() if not (v <= tol)}
-    assert not bad, f'parity failures (rel tol {tol}): {bad}'
+    assert not bad, f'parity failures (max-norm rel tol {tol}): {bad}'
+    miss = {k: v for k, v in elem.items() if not (v[0] <= elem_tol)}
+    noise = {}
+    if miss:
+        f_loss, f_logp, f_grads, f_gh0 = oracle_train(odec, tokens, h0, reward, scale, torch.float32)
+        f32 = {'logp': f_logp, 'grad_h0': f_gh0, **f_grads}
+        for k in miss:
+            a = np.asarray(pairs[k][0], dtype=np.float64).reshape(-1)
+            b = np.asarray(pairs[k][1], dtype=np.float64).reshape(-1)
+            c = np.asarray(f32[k], dtype=np.float64).reshape(-1)
+            den = np.abs(b) + 1e-2 * np.abs(b).max() + 1e-300
+            e_hip, e_f32 = np.abs(a - b) / den, np.abs(c - b) / den
+            over = e_hip > elem_tol
+            real = over & (e_hip > 3.0 * np.maximum(e_f32, elem_tol / 3.0))
+            assert not real.any(), (f'{k}: element-wise miss beyond fp32 summation noise at flat index '
+                                    f'{int(np.argmax(real))}: hip {e_hip[real].max():.3e} vs fp32 oracle '
+                                    f'{e_f32[real].max():.3e}')
+            noise[k] = dict(worst=float(e_hip.max()), n=int(over.sum()), fp32_oracle_worst=float(e_f32.max()))
+    report['elem'] = {k: v[0] for k, v in elem.items()}
+    report['noise'] = noise
     # parameters the loss cannot reach must stay without gradient
     assert all(not n.startswith('latent_to_hidden') for n in p_grads), p_grads.keys()
     return report
@@ -231,4 +268,4 @@ def run_smoke():
     assert torch.cuda.is_available(), 'smoke() needs a GPU'
     rep = check_train(TINY, B=20, T=9, seed=0)
     g = check_greedy(TINY, B=20, gen_len=12, seed=0)
-    print('smoke ok: max rel err', max(rep.values()), 'greedy', g)
+    print('smoke ok: max rel err', max(v for v in rep.values() if isinstance(v, float)), 'greedy', g)

@@ -96,3 +96,115 @@ def test_two_rank_gradient_exchange_equals_unsharded(tmp_path):
     assert np.abs(r0['g'] - g.numpy()).max() <= 1e-5 * np.abs(g.numpy()).max()
     assert np.abs(r0['p'] - p.numpy()).max() <= 1e-6
     assert abs(float(r0['loss']) - loss) <= 1e-5 * abs(loss)
+
+
+# ---------------------------------------------------------------------------------------------
+# dp.data_parallel_step: the whole data-parallel update (the function Reinforce.learn runs under a
+# process group), with an encoder whose gradients carry over between steps, a rank without any
+# valid molecule in one step, and a step in which no rank has one.
+# ---------------------------------------------------------------------------------------------
+N_STEPS = 4
+#            step 0                 step 1: rank 1 (rows 6..10) empty   step 2: nobody   step 3
+VALID = [[0, 1, 2, 4, 5, 6, 8, 9, 10], [0, 2, 3, 5],                    [],              [1, 4, 7, 8, 10]]
+
+
+class _Enc(torch.nn.Module):
+    """encoder(x) -> (mu, logvar); logvar never reaches the loss (reinforce.py:110)."""
+
+    def __init__(self):
+        super().__init__()
+        self.mu = torch.nn.Linear(5, PARAMS['latent_dim'])
+        self.lv = torch.nn.Linear(5, PARAMS['latent_dim'])
+
+    def forward(self, x):
+        return self.mu(x), self.lv(x)
+
+
+def _models():
+    dec = build_decoder(PARAMS, seed=0)
+    torch.manual_seed(9)
+    enc = _Enc()
+    opt = RL.make_optimizer(dec, dict(learning_rate=1e-2))
+    return dec, enc, opt
+
+
+def _latent(enc, n):
+    torch.manual_seed(4)
+    x = torch.randn(1, 5)
+    mu, _ = enc(x)
+    return torch.unsqueeze(mu.repeat(n, 1), 0)          # reinforce_omics.py:89-94
+
+
+def _reference_run():
+    """Single process, the reference's own order of operations (reinforce_omics.py:289-341): the
+    optimizer zeroes decoder gradients only, encoder gradients pile up, clip sees both."""
+    tokens, _, reward, _ = _inputs()
+    dec, enc, opt = _models()
+    out = []
+    for s in range(N_STEPS):
+        rows = VALID[s]
+        if not rows:
+            out.append((0.0, 0.0))
+            continue
+        opt.zero_grad()
+        latent = _latent(enc, B)
+        hidden = RL.initial_hidden(dec, latent, rows, 1)
+        loss = RL.reinforce_loss(dec, tokens[:, rows], hidden, reward[rows][:, None])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(dec.parameters()) + list(enc.parameters()), 0.1)
+        opt.step()
+        out.append((float(reward[rows].mean()), float(loss.item())))
+    return dec, enc, out
+
+
+def _dp_worker(rank, world, port, outdir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from paccmann_generator_amd import dp
+        torch.set_num_threads(1)
+        tokens, _, reward, _ = _inputs()
+        dec, enc, opt = _models()
+        lo, hi = dp.shard_range(B, rank, world)
+        res = []
+        for s in range(N_STEPS):
+            mine = [r for r in VALID[s] if lo <= r < hi]
+            local = [r - lo for r in mine]
+
+            def backward():
+                latent = _latent(enc, hi - lo)            # this rank encodes only its shard
+                hidden = RL.initial_hidden(dec, latent, local, 1)
+                loss = RL.reinforce_loss(dec, tokens[:, mine], hidden, reward[mine][:, None]) * len(mine)
+                loss.backward()
+                return loss.item()
+
+            r, l, n = dp.data_parallel_step(list(dec.parameters()), list(enc.parameters()), opt, backward,
+                                            len(mine), float(reward[mine].sum()) if mine else 0.0, 0.1)
+            assert n == len(VALID[s])
+            res.append((r, l))
+        np.savez(os.path.join(outdir, f'dp{rank}.npz'),
+                 p=torch.cat([p.detach().reshape(-1) for p in dec.parameters()]).numpy(),
+                 ge=torch.cat([p.grad.reshape(-1) for p in enc.mu.parameters()]).numpy(),
+                 lv_none=all(p.grad is None for p in enc.lv.parameters()), res=np.array(res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_with_encoder_empty_rank_and_empty_step(tmp_path):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / 'dp0.npz')
+    r1 = np.load(tmp_path / 'dp1.npz')
+    assert np.array_equal(r0['p'], r1['p']) and np.array_equal(r0['ge'], r1['ge'])   # replicas identical
+    dec, enc, out = _reference_run()
+    p = torch.cat([q.detach().reshape(-1) for q in dec.parameters()]).numpy()
+    ge = torch.cat([q.grad.reshape(-1) for q in enc.mu.parameters()]).numpy()
+    assert np.abs(r0['p'] - p).max() <= 2e-5, np.abs(r0['p'] - p).max()
+    # encoder gradients carried over 3 updates: equal to the single-process sum, NOT multiplied by the world size
+    assert np.abs(r0['ge'] - ge).max() <= 1e-4 * np.abs(ge).max()
+    assert bool(r0['lv_none']) and all(q.grad is None for q in enc.lv.parameters())
+    for (r, l), (rr, ll) in zip(r0['res'], out):
+        assert abs(r - rr) <= 1e-5 * max(1.0, abs(rr)) and abs(l - ll) <= 1e-4 * max(1.0, abs(ll))

@@ -31,7 +31,7 @@ loss = torch.empty(1, device=dev)
 st = _ffi.current_stream()
 
 def fwd():
-    _ffi.check(_ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(h0), _ffi._ptr(logp), None, _ffi._ptr(ws), st), 'fwd')
+    _ffi.check(_ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(h0), _ffi._ptr(logp), None, 0, _ffi._ptr(ws), st), 'fwd')
 def bwd(flags):
     _ffi.check(_ffi.lib.pmg_reinforce_bwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(rewards), 1.0 / B, flags, C.byref(gstruct), _ffi._ptr(gh0), _ffi._ptr(loss), _ffi._ptr(ws), st), 'bwd')
 def timed(fn, reps=3):

@@ -11,6 +11,6 @@ torch.manual_seed(1)
 latent = torch.randn(1, B, cfg['latent_dim'], device=dev)
 rewards = torch.rand(B, device=dev)
 ph = bench.time_phases(learner, cfg, latent, rewards, B, reps=int(os.environ.get('REPS', '5')))
-ph.pop('_steps')
+ph.pop('_steps'); ph.pop('_batch', None)
 print(os.path.basename(os.environ.get('PMG_LIB', 'libpmg.so')), ' '.join(f'{k}={v:.3f}' for k, v in ph.items()),
       f'sum={sum(ph.values()):.3f}', flush=True)

@@ -32,7 +32,7 @@ gh0 = torch.empty_like(h0)
 loss = torch.empty(1, device=dev)
 st = _ffi.current_stream()
 def fwd():
-    _ffi.check(_ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(h0), _ffi._ptr(logp), None, _ffi._ptr(ws), st), 'fwd')
+    _ffi.check(_ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(h0), _ffi._ptr(logp), None, 0, _ffi._ptr(ws), st), 'fwd')
 def bwd(flags):
     _ffi.check(_ffi.lib.pmg_reinforce_bwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(rewards), 1.0 / B, flags, C.byref(gstruct), _ffi._ptr(gh0), _ffi._ptr(loss), _ffi._ptr(ws), st), 'bwd')
 fwd(); bwd(_ffi.PMG_FLAG_SKIP_WGRAD); torch.cuda.synchronize()
