@@ -61,90 +61,94 @@ def all_reduce_gradients_(params: Iterable[torch.nn.Parameter], group=None) -> i
     sets of parameters -- or did not run at all -- still exchange buffers of one size.  Returns the
     number of floats reduced."""
     ps = list(params)
-    reduce_step_(ps, (), group=group, keep_none=False)
+    flat, _ = _reduce_flat(ps, [], group)
+    _scatter_grads(ps, flat, [True] * len(ps))
     return sum(p.numel() for p in ps)
 
 
-def reduce_step_(params: Sequence[torch.nn.Parameter], scalars: Sequence[float] = (), group=None,
-                 keep_none: bool = True) -> List[float]:
-    """The ONE data-path collective of a data-parallel REINFORCE step.
-
-    Flat fp32 buffer = [grad of every parameter in ``params`` (zeros where ``p.grad is None``) |
-    one has-gradient flag per parameter | ``scalars``], all-reduced (sum) in a single call.  The
-    summed gradients are written back to ``p.grad``; with ``keep_none`` a parameter that had no
-    gradient on ANY rank keeps ``grad = None`` (what a single process would have left).  Every rank
-    must call this with the same parameter list, including ranks with nothing to contribute (empty
-    shard, no valid molecule): they pass gradients of None and zero scalars.  Returns the summed
-    scalars."""
-    params = list(params)
-    if not params and not scalars:
-        return []
-    ref = next((p for p in params), None)
+def _reduce_flat(params: Sequence[torch.nn.Parameter], scalars: Sequence, group):
+    """[grad of every parameter (zeros where None) | has-gradient flag per parameter | scalars],
+    all-reduced (sum) in ONE call.  ``scalars`` may be host numbers or 0-dim device tensors (no
+    host synchronisation either way).  Returns (flat, number of tail entries)."""
+    ref = params[0] if params else None
     device = ref.device if ref is not None else torch.device('cpu')
     pieces = [(p.grad.detach().reshape(-1).to(torch.float32) if p.grad is not None
                else torch.zeros(p.numel(), dtype=torch.float32, device=device)) for p in params]
-    tail = torch.tensor([0.0 if p.grad is None else 1.0 for p in params] + [float(x) for x in scalars],
-                        dtype=torch.float32, device=device)
+    host = [0.0 if p.grad is None else 1.0 for p in params] + [0.0 if torch.is_tensor(x) else float(x) for x in scalars]
+    tail = torch.tensor(host, dtype=torch.float32).to(device, non_blocking=True)
+    for i, x in enumerate(scalars):
+        if torch.is_tensor(x):
+            tail[len(params) + i] = x.detach().to(device=device, dtype=torch.float32).reshape(())
     flat = torch.cat(pieces + [tail])
     all_reduce_(flat, group=group)
-    n_tail = tail.numel()
-    tail_h = flat[flat.numel() - n_tail:].cpu().tolist()
-    flags, out = tail_h[:len(params)], tail_h[len(params):]
+    return flat, tail.numel()
+
+
+def _scatter_grads(params, flat, take) -> None:
+    """``p.grad`` becomes a view of its slice of ``flat`` (no copies) for every parameter with take[i]."""
     off = 0
-    for p, has in zip(params, flags):
+    for p, t in zip(params, take):
         n = p.numel()
-        if has > 0.0 or not keep_none:
-            g = flat[off:off + n].view_as(p).to(p.dtype)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
+        if t:
+            g = flat[off:off + n].view_as(p)
+            p.grad = g if p.dtype == torch.float32 else g.to(p.dtype)
         off += n
-    return out
 
 
 def data_parallel_step(dec_params: Sequence[torch.nn.Parameter], enc_params: Sequence[torch.nn.Parameter],
-                       optimizer, backward_fn: Callable[[], float], num_mols: int, reward_sum: float,
-                       grad_clipping: Optional[float], group=None) -> Tuple[float, float, int]:
+                       optimizer, backward_fn: Callable[[], object], num_mols: int, reward_sum,
+                       grad_clipping: Optional[float], group=None):
     """One data-parallel REINFORCE update on this rank's shard (reinforce_omics.py:289-341 with the
     mean over valid molecules taken over ALL ranks).  Device-agnostic: the HIP operator (or, in the
     CPU tests, the oracle) comes in through ``backward_fn``.
 
     ``backward_fn()`` runs forward + backward with scale 1 on the ``num_mols`` valid molecules of this
     rank, leaves gradient SUMS in ``.grad`` and returns the loss sum; it is not called when
-    ``num_mols == 0``.  Then ONE all-reduce carries [gradients | flags | loss sum | reward sum | count]
-    (reduce_step_); every rank takes part, also one with nothing to contribute.  Everything is
-    divided by the global count, clip and the optimizer step run replicated.  When no rank has a valid
-    molecule the update is skipped everywhere.
+    ``num_mols == 0``.  The loss sum and ``reward_sum`` may be numbers or 0-dim tensors.  Then ONE all-reduce carries [gradients | has-gradient flags |
+    loss sum | reward sum | count]; every rank takes part, also one with nothing to contribute.
+    Everything is divided by the global count, clip and the optimizer step run replicated.  When no
+    rank has a valid molecule the update is skipped everywhere.
+
+    A rank that has valid molecules needs no host synchronisation here: its own count tells it that
+    the global count is positive, and a parameter without a gradient after its backward pass has
+    none on any rank (same graph everywhere).  Only a rank with nothing to contribute reads the
+    reduced flags and count back.
 
     Encoder gradients: the optimizer holds decoder parameters only (reinforce.py:44-45), so the
     reference never zeroes them and they carry over from step to step.  Only THIS step's
     contribution is summed over the ranks; the carried part is set aside before the backward pass
     and added back afterwards (summing it too would multiply it by the world size every step).
 
-    Returns (mean reward, loss, global valid count)."""
+    Returns (mean reward, loss) as 0-dim tensors on the parameters' device -- (0, 0) when the update
+    was skipped -- and the global valid count (a 0-dim tensor, or the int 0)."""
     dec_params, enc_params = list(dec_params), list(enc_params)
+    params = dec_params + enc_params
     optimizer.zero_grad()
     stash = [p.grad for p in enc_params]
     for p in enc_params:
         p.grad = None
-    loss_sum = float(backward_fn()) if num_mols > 0 else 0.0
-    loss_sum, reward_sum, n_glob = reduce_step_(dec_params + enc_params, (loss_sum, float(reward_sum), float(num_mols)),
-                                                group=group)
-    n_glob = int(round(n_glob))
-    if n_glob == 0:
-        for p, g in zip(enc_params, stash):
-            p.grad = g
-        optimizer.zero_grad()
-        return 0.0, 0.0, 0
+    loss_sum = backward_fn() if num_mols > 0 else 0.0
+    flat, n_tail = _reduce_flat(params, (loss_sum, reward_sum, float(num_mols)), group)
+    tail = flat[flat.numel() - n_tail:]
+    n_glob = tail[-1].clone()
+    if num_mols > 0:
+        take = [p.grad is not None for p in params]
+    else:
+        host = tail.cpu().tolist()
+        if int(round(host[-1])) == 0:
+            for p, g in zip(enc_params, stash):
+                p.grad = g
+            optimizer.zero_grad()
+            zero = torch.zeros((), dtype=torch.float32, device=flat.device)
+            return zero, zero.clone(), 0
+        take = [f > 0.0 for f in host[:len(params)]]
     inv = 1.0 / n_glob
-    fresh = [p.grad for p in dec_params + enc_params if p.grad is not None]
-    if fresh:
-        torch._foreach_mul_(fresh, inv)
+    flat.mul_(inv)                      # gradients, loss sum and reward sum -> means (flags/count unused after)
+    _scatter_grads(params, flat, take)
     for p, g in zip(enc_params, stash):
         if g is not None:
-            p.grad = g if p.grad is None else p.grad.add_(g)
+            p.grad = g if p.grad is None else g.add_(p.grad)
     if grad_clipping is not None:
-        torch.nn.utils.clip_grad_norm_(dec_params + enc_params, grad_clipping)
+        torch.nn.utils.clip_grad_norm_(params, grad_clipping)
     optimizer.step()
-    return reward_sum * inv, loss_sum * inv, n_glob
+    return tail[-2].clone(), tail[-3].clone(), n_glob

@@ -209,7 +209,7 @@ class Reinforce(object):
 
         With a process group these are this rank's shard and the step is data parallel: the kernel
         forms gradient SUMS (scale 1), ONE all-reduce carries [gradients | loss sum | reward sum |
-        valid count] (dp.reduce_step_), everything is divided by the global valid count afterwards,
+        valid count] (dp.data_parallel_step), everything is divided by the global valid count afterwards,
         and clip + Adam run replicated.  Every rank takes part in that collective, also a rank with
         no valid molecule (it contributes zeros); the update is skipped only when no rank has one."""
         dec = self.generator.decoder
@@ -236,9 +236,9 @@ class Reinforce(object):
 
         if ddp:
             r, l, _ = dp.data_parallel_step(dec_params, enc_params, self.optimizer, lambda: run(1.0), num_mols,
-                                            float(rewards_t.sum()) if num_mols > 0 else 0.0, self.grad_clipping,
+                                            rewards_t.sum() if num_mols > 0 else 0.0, self.grad_clipping,
                                             group=self.process_group)
-            return torch.tensor(r), torch.tensor(l)
+            return r, l
         self.optimizer.zero_grad()
         loss = run(1.0 / num_mols)
         summed_reward = torch.mean(rewards_t.float())
@@ -364,8 +364,9 @@ class ReinforceOmic(Reinforce):
 
 
 class ReinforceProtein(Reinforce):
-    """reinforce_proteins.py.  ``protein_df``: frame indexed by protein name whose row holds
-    the encoder input vector (reinforce_proteins.py:85-131 with encoder_uses_sequence=False)."""
+    """reinforce_proteins.py.  ``protein_df``: frame indexed by protein name whose columns
+    ``'0'..'767'`` hold the encoder input vector (reinforce_proteins.py:85-131 with
+    encoder_uses_sequence=False); a frame without those column names is taken whole."""
 
     def __init__(self, generator, encoder, predictor, protein_df, params, model_name, logger, **kw):
         self.predictor = predictor
@@ -378,7 +379,11 @@ class ReinforceProtein(Reinforce):
         """reinforce_proteins.py:60-83."""
         if protein is None:
             return torch.randn(1, batch_size, self.encoder.latent_size, device=self.device)
-        vec = np.asarray(self.protein_df.loc[protein].values, dtype=np.float32)
+        row = self.protein_df.loc[protein]
+        locations = [str(x) for x in range(768)]          # reinforce_proteins.py:124-128: embedding columns
+        if all(c in row.index for c in (locations[0], locations[-1])):
+            row = row[locations]                          # frames that also carry e.g. a 'Sequence' column
+        vec = np.asarray(row.values, dtype=np.float32)
         protein_tensor = torch.unsqueeze(torch.Tensor(vec), 0).to(self.device)
         protein_mu, protein_logvar = self.encoder(protein_tensor)
         return torch.unsqueeze(

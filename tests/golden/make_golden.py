@@ -30,13 +30,24 @@ if ROOT not in sys.path:
 from oracle import reinforce_loop as RL  # noqa: E402
 from oracle.philox import sample_row, uniform  # noqa: E402
 from oracle.stack_gru import GreedySearch, OracleGenerator, OracleStackGRUDecoder, build_decoder  # noqa: E402
-from tests.parity import CFG1, START, STOP, TINY, synthetic_tokens  # noqa: E402
+from tests.golden_util import sample_index, weight_checksum  # noqa: E402
+from tests.parity import CFG1, CFG2, CFG4, START, STOP, TINY, synthetic_tokens  # noqa: E402
 
 CASES = {
     # name: (params, B_train, T_train, B_decode, gen_len)
     'tiny_l1': (dict(TINY), 20, 9, 20, 12),
     'tiny_l2': (dict(TINY, n_layers=2), 19, 7, 17, 10),
     'cfg1': (dict(CFG1), 64, 100, 64, 100),
+}
+
+
+# Compact cases (BASELINE.json configs[1] and configs[3] model shapes at a length that crosses every
+# stack regime): weights are NOT stored -- they are build_decoder(params, seed=0), pinned by a
+# checksum -- and each parameter gradient is stored as <= 4096 evenly spaced samples plus its sum
+# and L2 norm, so that a 10-million-parameter case stays a small fixture.
+COMPACT = {
+    'cfg2_t130': (dict(CFG2), 18, 130, 24, 128),
+    'cfg4_t130': (dict(CFG4), 18, 130, 20, 110),
 }
 
 
@@ -69,12 +80,15 @@ def sampled_tokens(dec, latent, gen_len, temperature, seed):
     return out, margins
 
 
-def make_case(name, params, Bt, Tt, Bd, gen_len):
+def make_case(name, params, Bt, Tt, Bd, gen_len, compact=False):
     dec = build_decoder(params, seed=0)
     L, H = params['n_layers'], params['rnn_cell_size']
     out = {}
-    for k, v in dec.state_dict().items():
-        out['w.' + k] = v.numpy()
+    if compact:
+        out['w_checksum'] = weight_checksum(dec.state_dict())
+    else:
+        for k, v in dec.state_dict().items():
+            out['w.' + k] = v.numpy()
     out['params_keys'] = np.array(sorted(params.keys()))
     out['params_vals'] = np.array([-1 if params[k] is None else params[k] for k in sorted(params.keys())])
 
@@ -90,7 +104,7 @@ def make_case(name, params, Bt, Tt, Bd, gen_len):
     g64 = OracleGenerator(d64).generate_raw(latent.double(), torch.tensor([START]), torch.tensor([STOP]), gen_len,
                                             GreedySearch())
     out['dec.greedy_tokens_fp64'] = g64.numpy()
-    if name != 'cfg1':
+    if name != 'cfg1' and not compact:
         toks, margins = sampled_tokens(dec, latent, gen_len, 0.8, 1234)
         out['dec.sampled_tokens'] = toks
         out['dec.sampled_margin'] = margins
@@ -118,6 +132,7 @@ def make_case(name, params, Bt, Tt, Bd, gen_len):
     for n, p in d64.named_parameters():
         if p.grad is not None:
             out['grad.' + n] = p.grad.numpy()
+    full = {k[5:]: v for k, v in out.items() if k.startswith('grad.')}
     # fp32 round-off bound: the same computation in fp32 autograd
     h32 = h0.clone().requires_grad_(True)
     for p in dec.parameters():
@@ -126,7 +141,7 @@ def make_case(name, params, Bt, Tt, Bd, gen_len):
     worst = 0.0
     for n, p in dec.named_parameters():
         if p.grad is not None:
-            ref = out['grad.' + n]
+            ref = full[n]
             worst = max(worst, float(np.abs(p.grad.numpy() - ref).max() / (np.abs(ref).max() + 1e-30)))
     out['train.fp32_autograd_max_rel_err'] = np.float64(worst)
     # big float64 gradients are stored as float32 for the cfg1 case to keep the file small
@@ -134,6 +149,11 @@ def make_case(name, params, Bt, Tt, Bd, gen_len):
         for k in list(out):
             if k.startswith('grad.') or k.startswith('w.'):
                 out[k] = out[k].astype(np.float32)
+    if compact:
+        for n, gfull in full.items():
+            flat = out.pop('grad.' + n).reshape(-1)
+            out['gsample.' + n] = flat[sample_index(flat.size)]
+            out['gstat.' + n] = np.array([flat.sum(), np.sqrt((flat * flat).sum()), np.abs(flat).max()])
     path = os.path.join(HERE, name + '.npz')
     np.savez_compressed(path, **out)
     print(f'{name}: {os.path.getsize(path) / 1e6:.2f} MB, greedy fp32==fp64: '
@@ -142,5 +162,10 @@ def make_case(name, params, Bt, Tt, Bd, gen_len):
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
+    only = sys.argv[1:]
     for name, (params, Bt, Tt, Bd, gl) in CASES.items():
-        make_case(name, params, Bt, Tt, Bd, gl)
+        if not only or name in only:
+            make_case(name, params, Bt, Tt, Bd, gl)
+    for name, (params, Bt, Tt, Bd, gl) in COMPACT.items():
+        if not only or name in only:
+            make_case(name, params, Bt, Tt, Bd, gl, compact=True)

@@ -181,8 +181,8 @@ def _dp_worker(rank, world, port, outdir):
 
             r, l, n = dp.data_parallel_step(list(dec.parameters()), list(enc.parameters()), opt, backward,
                                             len(mine), float(reward[mine].sum()) if mine else 0.0, 0.1)
-            assert n == len(VALID[s])
-            res.append((r, l))
+            assert int(round(float(n))) == len(VALID[s])
+            res.append((float(r), float(l)))
         np.savez(os.path.join(outdir, f'dp{rank}.npz'),
                  p=torch.cat([p.detach().reshape(-1) for p in dec.parameters()]).numpy(),
                  ge=torch.cat([p.grad.reshape(-1) for p in enc.mu.parameters()]).numpy(),

@@ -77,3 +77,30 @@ def test_golden_fp32_noise_floor_is_far_below_tolerance():
     for name in GU.CASES:
         _, g = GU.load(name)
         assert float(g['train.fp32_autograd_max_rel_err']) < 1e-5
+
+
+@pytest.mark.parametrize('name', GU.COMPACT)
+def test_compact_cases_are_reproduced_by_the_fp32_oracle(name):
+    """configs[1] / configs[3] model shapes at T=130: weights from the seed (checksum pinned), greedy
+    tokens, log-probs, grad_h0 in full, parameter gradients as samples + statistics."""
+    params, g = GU.load(name)
+    dec = GU.compact_decoder(params, g)
+    latent = torch.from_numpy(g['dec.latent'])
+    gen_len = g['dec.greedy_tokens'].shape[1]
+    raw = OracleGenerator(dec).generate_raw(latent, torch.tensor([START]), torch.tensor([STOP]), gen_len,
+                                            GreedySearch())
+    assert (raw.numpy() == g['dec.greedy_tokens']).all()
+    assert (g['dec.greedy_tokens'] == g['dec.greedy_tokens_fp64']).all()
+    tokens = torch.from_numpy(g['train.tokens'])
+    h0 = torch.from_numpy(g['train.h0']).requires_grad_(True)
+    reward = torch.from_numpy(g['train.reward'])
+    loss = RL.reinforce_loss(dec, tokens, h0, reward[:, None])
+    loss.backward()
+    assert abs(loss.item() - float(g['train.loss'])) <= 1e-5 * abs(float(g['train.loss']))
+    assert rel_err(h0.grad.numpy(), g['train.grad_h0']) < 1e-5
+    named = dict(dec.named_parameters())
+    ref = GU.compact_grads(g)
+    assert set(ref) == {n for n, p in named.items() if p.grad is not None}
+    for n, (samples, stat) in ref.items():
+        GU.check_compact_grad(n, named[n].grad.numpy(), samples, stat, 1e-5)
+    assert float(g['train.fp32_autograd_max_rel_err']) < 1e-5

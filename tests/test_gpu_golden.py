@@ -69,3 +69,34 @@ def test_logprobs_and_gradients(gpu, name):
     assert set(got) == set(ref)
     for n, r in ref.items():
         assert rel_err(got[n].cpu().numpy(), r) < TOL, n
+
+
+@pytest.mark.parametrize('name', GU.COMPACT)
+def test_compact_cases_cfg2_cfg4_shapes(gpu, name):
+    """configs[1] (hidden 512) and configs[3] (2 layers, hidden 1024) model shapes at T=130 against
+    frozen vectors: greedy tokens bit-exact, log-probs / grad_h0 in full, every parameter gradient
+    through 4096 samples + its L2 norm and sum."""
+    from paccmann_generator_amd import Generator, GreedySearch, StackGRUDecoder, ops
+    params, g = GU.load(name)
+    odec = GU.compact_decoder(params, g)
+    dec = StackGRUDecoder(params)
+    dec.load_state_dict(odec.state_dict())
+    dec = dec.cuda().eval()
+    ref = g['dec.greedy_tokens']
+    tokens, lens = Generator(None, dec).generate_tokens(torch.from_numpy(g['dec.latent']), torch.tensor([START]),
+                                                        torch.tensor([STOP]), ref.shape[1], GreedySearch(),
+                                                        early_exit=False)
+    assert (tokens.cpu().numpy() == ref).all()
+    tok = torch.from_numpy(g['train.tokens']).cuda()
+    h0 = torch.from_numpy(g['train.h0']).cuda().requires_grad_(True)
+    reward = torch.from_numpy(g['train.reward']).cuda()
+    loss, logp = ops.reinforce_loss(dec.weights(), tok, h0, reward, float(g['train.scale']))
+    loss.backward()
+    assert abs(loss.item() - float(g['train.loss'])) <= TOL * abs(float(g['train.loss']))
+    assert rel_err(logp.cpu().numpy(), g['train.logp']) < TOL
+    assert rel_err(h0.grad.cpu().numpy(), g['train.grad_h0']) < TOL
+    got = {n: p.grad for n, p in dec.named_parameters() if p.grad is not None}
+    refg = GU.compact_grads(g)
+    assert set(got) == set(refg)
+    for n, (samples, stat) in refg.items():
+        GU.check_compact_grad(n, got[n].cpu().numpy(), samples, stat, TOL)

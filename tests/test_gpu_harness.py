@@ -145,6 +145,7 @@ def test_driver_loop_checkpoints_and_csv(gpu, tmp_path):
     assert len(ev) == n_steps and list(ev.columns[1:]) == ['loss', 'rewards']
     gen_csv = pd.read_csv(os.path.join(res, 'generated.csv'))
     assert set(gen_csv['mode']) == {'train', 'test'} and len(gen_csv) == len(rows)
+    assert list(gen_csv.columns[1:]) == ['cell_line', 'SMILES', 'IC50', 'mode']     # train_paccmann_rl.py:260-269
     after = learner.generator.decoder.state_dict()
     assert any(not torch.equal(before[k].cpu(), after[k].cpu()) for k in before)
     # checkpoints are plain state_dicts that load back into a fresh decoder (format unchanged)
@@ -203,3 +204,42 @@ def test_sets_variant_uses_mean_latent_and_no_clipping(gpu, tmp_path):
     assert abs(loss - o_loss) <= 1e-4 * abs(o_loss)
     for (n, po), (_, pp) in zip(odec.named_parameters(), learner.generator.decoder.named_parameters()):
         assert float((pp.detach().cpu() - po.detach()).abs().max()) < 0.02 * HP['learning_rate'], n
+
+
+def test_affinity_driver_preset_and_protein_embedding_columns(gpu, tmp_path):
+    """examples/affinity/train_conditional_generator.py:232-320: checkpoints every 10th epoch, one
+    held-out protein evaluated as 'eval' and never trained on, generated.csv with the columns
+    protein / SMILES / Binding probability / mode / Tox21.  The protein frame has the reference's
+    layout: a 'Sequence' column next to the embedding columns '0'..'767' (reinforce_proteins.py:124-128)."""
+    from paccmann_generator_amd import Generator, ReinforceProtein, driver
+    _, pdec = P.make_pair(PARAMS, seed=0)
+    torch.manual_seed(5)
+    enc = FakeEncoder(768, 16).cuda()
+    gen = Generator(enc, pdec)
+    gen._associate_language(FakeLanguage())
+    rng = np.random.RandomState(0)
+    df = pd.DataFrame(rng.randn(3, 768).astype(np.float32), index=['p0', 'p1', 'p2'],
+                      columns=[str(i) for i in range(768)])
+    df.insert(0, 'Sequence', ['MKV', 'MAA', 'MGG'])
+    hp = dict(HP, model_folder=str(tmp_path / 'bm'), epochs=10, steps=2, batch_size=24, eval_batch_size=16)
+    seen = []
+
+    def reward(smiles, target):
+        seen.append(target)
+        return reward_fn(smiles, target)
+
+    learner = ReinforceProtein(gen, enc, None, df, hp, 'aff', logging.getLogger('t'), is_valid=is_valid,
+                               reward_fn=reward, score_fn=lambda smiles, t: reward_fn(smiles, t))
+    with torch.no_grad():
+        z = learner.encode_protein('p1', 4)
+        mu, _ = enc(torch.tensor(df.loc['p1'][[str(i) for i in range(768)]].values.astype(np.float32)).cuda()[None])
+    assert torch.allclose(z[0, 0], mu[0]) and z.shape == (1, 4, 16)
+    rewards, losses, rows = driver.train(learner, list(df.index), ['p2'], hp, rng=np.random.RandomState(1),
+                                         log=lambda s: None, preset='affinity', tox_fn=lambda s: 1.0)
+    assert len(rewards) == 10 and 'p2' not in seen          # range(1, steps) per epoch; held-out never trained on
+    w = os.path.join(learner.model_path, 'weights')
+    assert os.path.exists(os.path.join(w, 'gen_10.pt')) and not os.path.exists(os.path.join(w, 'gen_9.pt'))
+    gen_csv = pd.read_csv(os.path.join(learner.model_path, 'results', 'generated.csv'))
+    assert list(gen_csv.columns[1:]) == ['protein', 'SMILES', 'Binding probability', 'mode', 'Tox21']
+    assert set(gen_csv['mode']) <= {'eval'} and set(gen_csv['protein']) <= {'p2'}
+    assert (gen_csv['Binding probability'] > 0.5).all()
