@@ -18,6 +18,18 @@
 #ifndef PMG_BWD_XPRE
 #define PMG_BWD_XPRE 1
 #endif
+// cache-policy bits (aux operand of the buffer instructions: 2 = nt) of the once-touched history
+// streams: saved gates (GT) and hidden history (HH) loads, gate-gradient (DG) stores.  Tuning knobs;
+// measured neutral at cfg2 (profiles/r02_experiments.md), so the default policy stays.
+#ifndef PMG_BWD_AUX_GT
+#define PMG_BWD_AUX_GT 0
+#endif
+#ifndef PMG_BWD_AUX_HH
+#define PMG_BWD_AUX_HH 0
+#endif
+#ifndef PMG_BWD_AUX_DG
+#define PMG_BWD_AUX_DG 0
+#endif
 
 namespace {
 
@@ -31,6 +43,11 @@ __device__ __forceinline__ void st4(float* p, const f32x4 v) {
 __device__ __forceinline__ f32x4 bl4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   const float4 v = pmg_bload(r, voff, soff);
   f32x4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; return o;
+}
+template <int AUX> __device__ __forceinline__ f32x4 bl4a(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const pmg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
+  f32x4 o; o.x = __uint_as_float(v.x); o.y = __uint_as_float(v.y); o.z = __uint_as_float(v.z); o.w = __uint_as_float(v.w);
+  return o;
 }
 
 // acc[t] += Wt[tile t][24 groups per chunk] * chunk columns.  24 reduction groups per chunk: 8 per
@@ -241,11 +258,11 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
           for (int cc = 0; cc < NCB; ++cc) {
             const unsigned c = (unsigned)(rd * NCB + cc);
             const unsigned gs = ((unsigned)(wave * UPW) + c) * 4096u;  // bytes: tile * 1024 floats
-            hr[cc] = bl4(gtr, voff, gs); hz[cc] = bl4(gtr, voff, gs + 1024u); hn[cc] = bl4(gtr, voff, gs + 2048u);
-            hg[cc] = bl4(gtr, voff, gs + 3072u);
+            hr[cc] = bl4a<PMG_BWD_AUX_GT>(gtr, voff, gs); hz[cc] = bl4a<PMG_BWD_AUX_GT>(gtr, voff, gs + 1024u);
+            hn[cc] = bl4a<PMG_BWD_AUX_GT>(gtr, voff, gs + 2048u); hg[cc] = bl4a<PMG_BWD_AUX_GT>(gtr, voff, gs + 3072u);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              hp[cc][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(hhr, vrow, (c * 256u + j * 16u) * 4u, 0));
+              hp[cc][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(hhr, vrow, (c * 256u + j * 16u) * 4u, PMG_BWD_AUX_HH));
           }
 #pragma unroll
           for (int cc = 0; cc < NCB; ++cc) {
@@ -271,10 +288,10 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const unsigned so = ((unsigned)c * 256u + j * 16u) * 4u, gH = (unsigned)H * 64u;
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dr_pre[j]), dgr, vrow, so, 0);
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz_pre[j]), dgr, vrow, so + gH, 0);
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dn_pre[j]), dgr, vrow, so + 2u * gH, 0);
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dghn[j]), dgr, vrow, so + 3u * gH, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dr_pre[j]), dgr, vrow, so, PMG_BWD_AUX_DG);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz_pre[j]), dgr, vrow, so + gH, PMG_BWD_AUX_DG);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dn_pre[j]), dgr, vrow, so + 2u * gH, PMG_BWD_AUX_DG);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dghn[j]), dgr, vrow, so + 3u * gH, PMG_BWD_AUX_DG);
             }
           }
           PMG_TICK(0)

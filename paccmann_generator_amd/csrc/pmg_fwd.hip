@@ -34,10 +34,15 @@ __device__ __forceinline__ f32x4 bl4(__amdgpu_buffer_rsrc_t r, unsigned voff, un
   const float4 v = pmg_bload(r, voff, soff);
   f32x4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; return o;
 }
+// history stores of the teacher-forced pass (gates, hidden): written once, read once by the backward
+// much later; PMG_FWD_AUX_HIST = cache-policy bits of those stores (2 = nt).  Tuning knob.
+#ifndef PMG_FWD_AUX_HIST
+#define PMG_FWD_AUX_HIST 0
+#endif
 __device__ __forceinline__ void bs4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const f32x4 v) {
   pmg_u32x4 u;
   u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
-  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, PMG_FWD_AUX_HIST);
 }
 // stack slab streams: cache-policy bits of the buffer instruction (bit 1 = nt) as a tuning knob
 #ifndef PMG_STACK_AUX_LD
@@ -57,7 +62,7 @@ __device__ __forceinline__ void bs4s(__amdgpu_buffer_rsrc_t r, unsigned voff, co
   __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, 0, PMG_STACK_AUX_ST);
 }
 __device__ __forceinline__ void bs1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, PMG_FWD_AUX_HIST);
 }
 
 // acc{r,z,t}[u0..u0+TPP) += W[tiles 3*u0 ..] * X   over KG groups of 16 columns.
