@@ -166,13 +166,10 @@ class Reinforce(object):
         if table is not None:
             tokens, lens = self.sample_tokens(latent)
             strings = ops.detokenize(table, tokens, lens)
-            # rows + 2 x stop, cut out of one device-built matrix: one masked select, one copy to the
-            # host, one split (B Python-level slices cost more than the decode itself at B=4096)
-            padded = pad_rows_on_device(tokens, lens, lang.stop_index, t_max=tokens.shape[1] + 2).t()
-            sizes = lens.to(torch.int64) + 2
-            keep_pos = torch.arange(padded.shape[1], device=padded.device).unsqueeze(0) < sizes.unsqueeze(1)
-            numericals = list(padded[keep_pos].cpu().split(sizes.cpu().tolist()))
-            self._last_sample = (tokens, lens, numericals)      # lets _policy_gradient pad on the device
+            # rows + 2 x stop (reinforce.py:177-184) as a lazy sequence over one host copy of the token
+            # matrix: B tensor objects cost more than the decode itself at B=4096, and the learner pads
+            # the valid rows on the device anyway (_padded_valid)
+            numericals = StopRows(tokens, lens, lang.stop_index)
         else:
             mols_numerical = self.generator.generate(
                 self._decoder_latent(latent),
@@ -197,7 +194,8 @@ class Reinforce(object):
         keep = [i for i in range(len(ok)) if not (remove_invalid and not ok[i])]
         if self.logger is not None:
             self.logger.info(f'{self.model_name}: SMILES validity: {100.0 * sum(ok) / max(1, len(ok)):.2f}%.')
-        return [smiles[i] for i in keep], [numericals[i] for i in keep], valid_idxs
+        nums = numericals.subset(keep) if isinstance(numericals, StopRows) else [numericals[i] for i in keep]
+        return [smiles[i] for i in keep], nums, valid_idxs
 
     # ------------------------------------------------------------------ learning
     def learn(self, latent_z, padded_nums, valid_idx, rewards, lrps: int = 1):
@@ -277,15 +275,11 @@ class Reinforce(object):
         """pad_sequence(valid_nums) (reinforce_omics.py:304).  When the rows are the ones the device
         detokeniser path just produced, the same [T_max, B_valid] matrix is built on the device from
         the decoded tokens instead of from B_valid host tensors."""
-        last = getattr(self, '_last_sample', None)
-        self._last_sample = None
-        if last is not None and len(valid_nums) == len(valid_idx) and len(valid_idx) > 0 and \
-                all(valid_nums[j] is last[2][i] for j, i in ((0, valid_idx[0]), (-1, valid_idx[-1]))):
-            tokens, lens, _ = last
-            idx = torch.as_tensor(valid_idx, dtype=torch.long, device=tokens.device)
+        if isinstance(valid_nums, StopRows) and len(valid_idx) > 0 and valid_nums.index == list(valid_idx):
+            idx = torch.as_tensor(valid_idx, dtype=torch.long, device=valid_nums.tokens.device)
             self._tokens_trusted = True      # rows cut from pmg_decode's own output: ids are in range
-            return pad_rows_on_device(tokens.index_select(0, idx), lens.index_select(0, idx),
-                                      self.generator.smiles_language.stop_index)
+            return pad_rows_on_device(valid_nums.tokens.index_select(0, idx), valid_nums.lens.index_select(0, idx),
+                                      valid_nums.stop_index)
         self._tokens_trusted = False
         return torch.nn.utils.rnn.pad_sequence(valid_nums)
 
@@ -439,6 +433,41 @@ class ReinforceMultiModalSets(Reinforce):
         """reinforce_sets.py:438-502."""
         latent_z = self.encode_set(cell_line, protein, self._local_batch(batch_size))
         return self._policy_gradient(latent_z, (protein, cell_line))
+
+
+class StopRows:
+    """The list of 1-D token tensors ``row[:len] + [stop, stop]`` the reference builds at
+    reinforce.py:177-184, as a lazy sequence over the decoded [B, generate_len] matrix: rows are cut
+    (from one host copy, made on first use) only when somebody indexes or iterates.  Keeps the device
+    tensors, so that the learner can pad the selected rows without a host round trip."""
+
+    def __init__(self, tokens: torch.Tensor, lens: torch.Tensor, stop_index: int, index=None):
+        self.tokens, self.lens, self.stop_index = tokens, lens, int(stop_index)
+        self.index = list(range(tokens.shape[0])) if index is None else list(index)
+        self._host = None
+
+    def subset(self, keep):
+        out = StopRows(self.tokens, self.lens, self.stop_index, [self.index[i] for i in keep])
+        out._host = self._host
+        return out
+
+    def _rows(self):
+        if self._host is None:
+            self._host = (self.tokens.cpu(), self.lens.cpu().tolist(), torch.tensor(2 * [self.stop_index]))
+        return self._host
+
+    def __len__(self):
+        return len(self.index)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return self.subset(range(len(self.index))[i])
+        tok, lens, stops = self._rows()
+        r = self.index[i]
+        return torch.cat([tok[r, :lens[r]], stops])
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self.index)))
 
 
 def pad_rows_on_device(tokens: torch.Tensor, lens: torch.Tensor, stop_index: int, t_max: Optional[int] = None):
