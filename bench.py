@@ -264,7 +264,8 @@ def main():
         backend = os.environ.get('PMG_DIST_BACKEND', 'nccl')
         local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend)
+        # device_id binds the communicator to this rank's GPU up front (no device guessing in barrier())
+        dist.init_process_group(backend, **({'device_id': torch.device('cuda', local_rank)} if backend == 'nccl' else {}))
         pg = dist.group.WORLD
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)

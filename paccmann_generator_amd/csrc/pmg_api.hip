@@ -220,6 +220,7 @@ extern "C" int pmg_decode(const pmg_shape* s, const pmg_weights* w, const float*
   FwdArgs a;
   fill_fwd_common(&a, d, lay, base);
   a.mode = PMG_FWD_DECODE;
+  a.KL = pmg_fwd_stack_rows(&a);
   a.N = gen_len;
   a.start_tok = start_tok; a.stop_tok = stop_tok; a.temperature = temperature; a.flags = flags;
   a.seed = philox_seed; a.offset = philox_offset; a.seq_base = seq_index_base;
@@ -302,6 +303,7 @@ extern "C" int pmg_logprob_fwd(const pmg_shape* s, const pmg_weights* w, const i
   fill_fwd_common(&a, d, lay, base);
   fill_history(&a, d, lay, base);
   a.mode = PMG_FWD_TEACHER;
+  a.KL = pmg_fwd_stack_rows(&a);
   a.N = d.T - 1;
   a.h0 = h0; a.tok_in = tokens; a.logp_out = logp_out; a.h_out = h_out;
   HIPCHK(pmg_launch_fwd(&a, st));
@@ -328,6 +330,7 @@ extern "C" int pmg_step(const pmg_shape* s, const pmg_weights* w, const int64_t*
   FwdArgs a;
   fill_fwd_common(&a, d, lay, base);
   a.mode = PMG_FWD_STEP;
+  a.KL = 0;
   a.N = 1;
   a.h0 = hidden_in; a.tok_in = tok; a.stack_in = stack_in;
   a.h_out = hidden_out; a.stack_out = stack_out; a.logits_out = logits_out;

@@ -86,33 +86,48 @@ struct NoSide {
   template <int U> __device__ __forceinline__ void step() const {}
 };
 
-// Stack update of one thread: column (w, 4 sequences), rows d0 .. d0+rows-1, one row per call.
+// Stack update of one thread: column (w, 4 sequences), rows d0 .. d1-1, one row per call.
 //   new[d] = no_op*old[d] + push*old[d-1] + pop*old[d+1]
-// q[] is a ring of old rows requested ahead (slot of old[d0+1+k] is (k-1)&3); loads are
-// unconditional at a clamped row and masked when consumed (rows beyond old_hi read as zero).
+// Rows d < KL of the stack live in LDS and are updated IN PLACE (a thread walks upward with
+// old[d-1], old[d] in registers and old[d+1] requested ahead, so it never reads what it has
+// written); deeper rows live in the workgroup's global ping-pong slab.  A depth part is either all
+// LDS or all global (wave-uniform `lds`), and the only rows a thread needs from outside its own
+// range -- old[d0-1] and old[d1] -- are read before barrier B1, i.e. before anybody writes
+// (s_end = old[d1]).  q[] is a ring of own rows requested ahead (slot of old[d0+1+k] is (k-1)&3).
 struct StackSide {
   static constexpr bool kActive = true;
-  __amdgpu_buffer_rsrc_t Sold, Snew;  // old / new stack slab of this row group
+  __amdgpu_buffer_rsrc_t Sold, Snew;  // old / new global stack slab of this row group
   unsigned vcol;                      // byte offset of this thread's column inside a stack row
-  f32x4 anoop, apush, apop, s_prev, s_cur, q[4];
-  int d0, rows, old_hi, Dm1, sj, dch;  // dch: calls after which every thread of the workgroup is done
-  unsigned rstr;  // floats per stack row slab line: W*16
-  bool on;
+  float* sl;                          // LDS: this thread's column of stack row 0
+  f32x4 anoop, apush, apop, s_prev, s_cur, s_end, q[4];
+  int d0, d1, rows, old_hi, sj, dch;  // dch: calls after which every thread of the workgroup is done
+  unsigned rstr;  // floats per stack row: W*16
+  bool on, lds, hist;  // lds: own rows in LDS (wave-uniform); hist: new rows are also kept in the global slab
+  __device__ __forceinline__ f32x4 ldrow(const int d) const {
+    if (lds) return ld4(sl + (size_t)d * rstr);
+    return bl4s(Sold, (unsigned)d * rstr * 4u + vcol);
+  }
+  __device__ __forceinline__ void strow(const int d, const f32x4 v) const {
+    if (lds) {
+      st4(sl + (size_t)d * rstr, v);
+      if (hist) bs4s(Snew, (unsigned)d * rstr * 4u + vcol, v);
+    } else {
+      bs4s(Snew, (unsigned)d * rstr * 4u + vcol, v);
+    }
+  }
   template <int U> __device__ __forceinline__ void step() {
     if (sj >= dch) return;  // uniform: nothing left for anybody
     const int d = d0 + sj;
     f32x4 nxt = q[U];
     if (sj + 4 < dch) {  // uniform: somebody will consume this slot again
       const int dn = d + 5;
-      const int dc = dn < Dm1 ? dn : Dm1;
-      q[U] = bl4s(Sold, (unsigned)dc * rstr * 4u + vcol);
+      q[U] = ldrow(dn < d1 ? dn : d1 - 1);  // own rows only
     }
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    nxt = (d + 1 == d1) ? s_end : nxt;
     nxt = (d + 1 <= old_hi) ? nxt : z4;
     const f32x4 nw = anoop * s_cur + apush * s_prev + apop * nxt;
-    if (on && sj < rows) {
-      bs4s(Snew, (unsigned)d * rstr * 4u + vcol, nw);
-    }
+    if (on && sj < rows) strow(d, nw);
     s_prev = s_cur;
     s_cur = nxt;
     ++sj;
@@ -361,6 +376,7 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
   float* xex = xtop + 16 * PMG_XTP;                      // [16][XP]
   int* misc = reinterpret_cast<int*>(xex + 16 * XP);     // [0..15] token, [16] all-done flag
   float* lat = reinterpret_cast<float*>(misc + 32);      // decode only: [16][Z+8]
+  float* slds = lat + (MODE == PMG_FWD_DECODE ? 16 * (a.Z + 8) : 0);  // [KL][W*16] top rows of the stack
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -435,26 +451,16 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
 
   f32x4 ar[UPW], az[UPW], ai[UPW], ah[UPW];
 
-  // stack update work split: thread -> (column w, row quad bq, depth part); the depth range of a
-  // part is recomputed every step from the number of live rows (see below)
-  int st_bq, st_w, st_part, st_dsplit;
-  bool st_col;
-  size_t st_cofs;
-  {
-    const int ncol = W * 4;  // <= 256 (pmg_check_shape caps W at 64): one item per thread
-    // PMG_STACK_THREADS: threads that take part in the stack update.  Restricting it to waves 0-3
-    // (which the issue arbiter favours, so they finish the W_hh product early) was measured and
-    // was slower: waves 4-7 do not speed up when relieved of the side job.
-    st_dsplit = (PMG_STACK_THREADS < NTHR ? PMG_STACK_THREADS : NTHR) / ncol;
-    if (st_dsplit < 1) st_dsplit = 1;
-    if (st_dsplit > D) st_dsplit = D;
-    st_bq = tid & 3;
-    const int cw = tid >> 2;
-    st_w = cw % W;
-    st_part = cw / W;
-    st_col = tid < ncol * st_dsplit;
-    st_cofs = (size_t)st_w * 16 + 4 * st_bq;
-  }
+  // stack update work split: thread -> (column w, row quad bq, depth part).  Two depth parts, one
+  // per half of the workgroup (waves 0-3 / 4-7), so that where a part's rows live (LDS or global) is
+  // wave-uniform; the depth range of a part is recomputed every step from the number of live rows.
+  const int KL = a.KL;               // stack rows kept in LDS (0: none)
+  const int st_part = wave >> 2;     // scalar
+  const int st_bq = tid & 3;
+  const int st_cw = (tid & 255) >> 2;
+  const bool st_col = st_cw < W;
+  const int st_w = st_col ? st_cw : 0;
+  const size_t st_cofs = (size_t)st_w * 16 + 4 * st_bq;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   NoSide no_side;
   float4 wpre[3 * TPP];        // weight group prefetched for the product that runs next (see gemm3)
@@ -492,31 +498,43 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
       if (s_zero && i < st_hi) st_hi = i;
     }
     const int st_nrows = st_hi + 1;
-    const int st_dch = (st_nrows + st_dsplit - 1) / st_dsplit;
-    const int st_d0 = st_part * st_dch;
-    const int st_d1 = (st_d0 + st_dch < st_nrows) ? st_d0 + st_dch : st_nrows;
+    // Depth parts: [0, bnd) for waves 0-3, [bnd, nrows) for waves 4-7.  With more live rows than fit
+    // in LDS the cut is the LDS boundary (part 0 all LDS, part 1 all global), otherwise the middle
+    // (both parts in LDS); without LDS rows (KL = 0) both parts are global.
+    const int st_bnd = (KL > 0 && st_nrows > KL) ? KL : ((st_nrows + 1) >> 1);
+    const int st_d0 = st_part ? st_bnd : 0;
+    const int st_d1 = st_part ? st_nrows : st_bnd;
+    const int st_dch = (st_bnd > st_nrows - st_bnd) ? st_bnd : st_nrows - st_bnd;
     const int st_rows = st_d1 - st_d0;
+    const bool st_own_lds = KL > 0 && (st_part == 0 || st_nrows <= KL);  // scalar
     const bool st_on = st_col && st_d0 < st_d1 && !(dbg & 0x100) && i < N;
     // target token of step i-1 (teacher): requested here, used after the extras GEMM
     int cs_y = 0;
     if (teacher && i >= 1 && row0 + cs_bb < B) cs_y = min(max((int)a.tok_in[(size_t)i * B + row0 + cs_bb], 0), V - 1);
 
-    // old rows d0-1, d0, d0+1 (first row of this thread) and the ring d0+2 .. d0+5: requested here,
-    // unconditionally at clamped rows (inactive threads read row 0 of their column), masked when used
+    // old rows d0-1, d0, d0+1 (first row of this thread), d1 (first row of the part above) and the ring
+    // d0+2 .. d0+5: requested here, before barrier B1, i.e. before anybody overwrites an LDS row; only
+    // rows that hold data are requested (memory operations are not free here), the rest stay zero
     StackSide stk;
-    stk.Sold = st_Sold; stk.vcol = st_vcol; stk.rstr = (unsigned)W * 16u; stk.Dm1 = D - 1;
-    stk.d0 = st_on ? st_d0 : 0; stk.dch = st_dch; stk.rows = st_rows; stk.old_hi = st_old_hi; stk.on = st_on;
+    stk.Sold = st_Sold; stk.vcol = st_vcol; stk.rstr = (unsigned)W * 16u; stk.sl = slds + st_cofs;
+    stk.d0 = st_on ? st_d0 : 0; stk.d1 = st_on ? st_d1 : 1; stk.dch = st_dch; stk.rows = st_rows;
+    stk.old_hi = st_old_hi; stk.on = st_on; stk.lds = st_own_lds; stk.hist = keep;
     f32x4 st_pm = zero4, st_c0 = zero4, st_n0 = zero4;
+    stk.s_end = zero4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) stk.q[j] = zero4;
-    if (st_on) {  // only rows that hold data are requested (memory operations are not free here)
+    if (st_on) {
       const unsigned rb = stk.rstr * 4u;
-      if (st_d0 > 0 && st_d0 - 1 <= st_old_hi) st_pm = bl4s(st_Sold, (unsigned)(st_d0 - 1) * rb + st_vcol);
-      if (st_d0 <= st_old_hi) st_c0 = bl4s(st_Sold, (unsigned)st_d0 * rb + st_vcol);
-      if (st_d0 + 1 <= st_old_hi) st_n0 = bl4s(st_Sold, (unsigned)(st_d0 + 1) * rb + st_vcol);
+      // rows outside the own range live where THEIR depth says: LDS below KL, the global slab above
+      if (st_d0 > 0 && st_d0 - 1 <= st_old_hi)
+        st_pm = (st_d0 - 1 < KL) ? ld4(stk.sl + (size_t)(st_d0 - 1) * stk.rstr) : bl4s(st_Sold, (unsigned)(st_d0 - 1) * rb + st_vcol);
+      if (st_d1 <= st_old_hi && st_d1 < D)
+        stk.s_end = (st_d1 < KL) ? ld4(stk.sl + (size_t)st_d1 * stk.rstr) : bl4s(st_Sold, (unsigned)st_d1 * rb + st_vcol);
+      if (st_d0 <= st_old_hi) st_c0 = stk.ldrow(st_d0);
+      if (st_d0 + 1 <= st_old_hi && st_d0 + 1 < st_d1) st_n0 = stk.ldrow(st_d0 + 1);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (st_d0 + 2 + j <= st_old_hi && j + 1 < st_dch) stk.q[j] = bl4s(st_Sold, (unsigned)(st_d0 + 2 + j) * rb + st_vcol);
+        if (st_d0 + 2 + j <= st_old_hi && st_d0 + 2 + j < st_d1) stk.q[j] = stk.ldrow(st_d0 + 2 + j);
     }
 
     // ------------------------------------------------------------ extras GEMM
@@ -657,10 +675,10 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
     {
       const f32x4 pm = (st_d0 == 0) ? pv : ((st_d0 - 1 <= st_old_hi) ? st_pm : zero4);
       const f32x4 c0 = (st_d0 <= st_old_hi) ? st_c0 : zero4;
-      const f32x4 n0 = (st_d0 + 1 <= st_old_hi) ? st_n0 : zero4;
+      const f32x4 n0 = (st_d0 + 1 <= st_old_hi) ? ((st_d0 + 1 == st_d1) ? stk.s_end : st_n0) : zero4;
       if (st_on) {
         const f32x4 nw = anoop * c0 + apush * pm + apop * n0;
-        bs4s(st_Snew, (unsigned)st_d0 * stk.rstr * 4u + st_vcol, nw);
+        stk.strow(st_d0, nw);
         if (st_d0 == 0) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) xtop[(4 * st_bq + j) * PMG_XTP + st_w] = nw[j];
@@ -824,11 +842,29 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
 
 }  // namespace
 
-size_t pmg_fwd_lds_bytes(const FwdArgs* a) {
+static size_t fwd_lds_base_bytes(const FwdArgs* a) {
   size_t fl = (size_t)a->L * 16 * a->HP + 16 * PMG_XTP + (size_t)16 * a->XP + 32;
   if (a->mode == PMG_FWD_DECODE) fl += (size_t)16 * (a->Z + 8);
   return fl * sizeof(float);
 }
+
+// PMG_FWD_LDS_STACK=0 keeps the whole stack in the global slab (A/B knob)
+#ifndef PMG_FWD_LDS_STACK
+#define PMG_FWD_LDS_STACK 1
+#endif
+
+// Stack rows kept in LDS: as many of the top rows as fit next to the hidden state in the CU's
+// 160 KiB (a row is W x 16 sequences x 4 B).  The single-step form keeps none: its stack comes from
+// and goes back to the caller's memory.
+int pmg_fwd_stack_rows(const FwdArgs* a) {
+  if (!PMG_FWD_LDS_STACK || a->mode == PMG_FWD_STEP) return 0;
+  const size_t base = fwd_lds_base_bytes(a), row = (size_t)a->W * 64;
+  if (base + row > (size_t)160 * 1024) return 0;
+  const size_t k = ((size_t)160 * 1024 - base) / row;
+  return (int)(k < (size_t)a->D ? k : (size_t)a->D);
+}
+
+size_t pmg_fwd_lds_bytes(const FwdArgs* a) { return fwd_lds_base_bytes(a) + (size_t)a->KL * a->W * 64; }
 
 template <int WV, int UPW, int TPP, int MODE, bool MULTI>
 static hipError_t launch_fwd_t(const FwdArgs* a, hipStream_t st) {

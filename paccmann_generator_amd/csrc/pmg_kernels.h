@@ -47,6 +47,7 @@ struct FwdArgs {
   int dbg;    // ablation bits, -DPMG_ABLATE builds only (always 0 in the default library)
   int B, G, N;  // N decoder steps
   int H, W, D, V, L, Z, NX, NXT, XP, HP, KGH, VP, SW;
+  int KL;     // top rows of the stack kept in LDS (pmg_fwd_stack_rows)
   int start_tok, stop_tok;
   float temperature;
   uint32_t flags;
@@ -79,6 +80,7 @@ struct FwdArgs {
 
 hipError_t pmg_launch_fwd(const FwdArgs* a, hipStream_t st);
 size_t pmg_fwd_lds_bytes(const FwdArgs* a);
+int pmg_fwd_stack_rows(const FwdArgs* a);
 
 // ------------------------------------------------------------------ backward
 struct BwdArgs {

@@ -67,6 +67,17 @@ def test_parity_edge_shapes(gpu, over):
     assert P.check_greedy(cfg, 19, 9)['mismatched_rows'] == 0
 
 
+def test_parity_deep_wide_stack_crosses_the_lds_boundary(gpu):
+    """A stack that is wider and deeper than the LDS rows the forward can keep next to the hidden
+    state (W=64: 4 KB per row, 40 rows live at T=90): the update runs partly in LDS (in place) and
+    partly in the global ping-pong slab, through every regime of live rows."""
+    cfg = dict(P.TINY, stack_width=64, stack_depth=40, vocab_size=30)
+    P.check_train(cfg, B=19, T=90, tol=TOL)
+    assert P.check_greedy(cfg, 21, 88)['mismatched_rows'] == 0
+    r = P.check_sampling(cfg, 18, 85, temperature=0.9)
+    assert r['boundary'] <= 2
+
+
 def test_train_parity_cfg1(gpu):
     P.check_train(P.CFG1, B=64, T=100, tol=TOL)
 
