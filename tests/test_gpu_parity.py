@@ -151,7 +151,7 @@ def test_early_exit_only_changes_tokens_after_stop(gpu):
         assert torch.equal(full[r, :n + 1], cut[r, :n + 1])
 
 
-def test_gradient_accumulate_and_h0_grad_flow(gpu):
+def test_h0_gradient_flows_into_latent_to_hidden(gpu):
     """grad_h0 reaches latent_to_hidden through torch autograd (reinforce_omics.py:313, :335)."""
     from paccmann_generator_amd import ops
     odec, pdec = P.make_pair(P.TINY)

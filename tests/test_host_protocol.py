@@ -92,3 +92,25 @@ def test_reinforce_refuses_a_cpu_decoder(tmp_path):
     gen = Generator(None, StackGRUDecoder(PARAMS))
     with pytest.raises(RuntimeError, match='no CPU path'):
         Reinforce(gen, None, dict(model_folder=str(tmp_path)), 'm', logging.getLogger('t'))
+
+
+def test_stop_rows_is_the_lazy_twin_of_the_reference_row_list():
+    """reinforce.py:177-184: every sampled row gets 2 x [stop_index] appended.  StopRows builds those
+    rows on demand from the decoded matrix; indexing, iteration, slicing and subset selection must
+    give what the reference's list comprehension gives."""
+    from paccmann_generator_amd.reinforce import StopRows
+    g = torch.Generator().manual_seed(0)
+    tokens = torch.randint(4, 20, (7, 9), generator=g)
+    lens = torch.tensor([0, 3, 9, 1, 5, 9, 2], dtype=torch.int32)
+    stop = 3
+    ref = [torch.cat([tokens[i, :int(lens[i])], torch.tensor([stop, stop])]) for i in range(7)]
+    rows = StopRows(tokens, lens, stop)
+    assert len(rows) == 7
+    assert all(torch.equal(a, b) for a, b in zip(rows, ref))
+    assert torch.equal(rows[2], ref[2]) and torch.equal(rows[-1], ref[-1])
+    sub = rows.subset([1, 4, 6])
+    assert len(sub) == 3 and sub.index == [1, 4, 6]
+    assert all(torch.equal(a, ref[i]) for a, i in zip(sub, [1, 4, 6]))
+    assert [r.tolist() for r in rows[1:3]] == [ref[1].tolist(), ref[2].tolist()]
+    padded = torch.nn.utils.rnn.pad_sequence(list(sub))          # reinforce_omics.py:304 accepts it
+    assert padded.shape == (7, 3) and padded[:, 0].tolist() == ref[1].tolist() + [0, 0]
