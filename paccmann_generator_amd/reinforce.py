@@ -249,11 +249,14 @@ class Reinforce(object):
 
     def _policy_gradient(self, latent_z, target):
         B_local = latent_z.shape[1]
-        if B_local > 0:
-            valid_smiles, valid_nums, valid_idx = self.get_smiles_from_latent(latent_z, remove_invalid=True)
-        else:   # empty shard (global batch smaller than the world): keep the Philox offset in step
-            self.generator.skip_draws(self.generate_len)
-            valid_smiles, valid_nums, valid_idx = [], [], []
+        try:
+            if B_local > 0:
+                valid_smiles, valid_nums, valid_idx = self.get_smiles_from_latent(latent_z, remove_invalid=True)
+            else:   # empty shard (global batch smaller than the world): keep the Philox offset in step
+                self.generator.skip_draws(self.generate_len)
+                valid_smiles, valid_nums, valid_idx = [], [], []
+        finally:
+            self._seq_base = 0   # the shard's base holds for this step's decode only
         if len(valid_nums) == 0:
             if self.logger is not None:
                 self.logger.warning('no valid molecule in the batch' +
