@@ -60,7 +60,7 @@ static void make_layout(const PmgDims& d, int mode, PmgLayout* L) {
     }
     L->CT = take((T - 1) * G * 64);
     L->PV = take((T - 1) * G * 1024);
-    L->TP = take((T - 1) * G * 1024);
+    L->TP = take((T - 1) * G * 2048);  // [64 stack-top rows | 64 one-hot token rows][16]
     L->PR = take((T - 1) * G * (size_t)d.VP * 16);
     L->DX = take(T * G * (size_t)d.NXT * 16 * 16);
     L->DS = take(2 * G * (size_t)d.SW);

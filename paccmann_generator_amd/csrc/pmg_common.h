@@ -99,7 +99,7 @@ struct PmgLayout {
   // history (train)
   size_t HH[PMG_MAX_LAYERS];  // [T][G][H][16]
   size_t GT[PMG_MAX_LAYERS];  // [T-1][G][UT][4][64][4]
-  size_t CT, PV, TP, PR;      // [T-1][G][{4,64,64,VP}][16]
+  size_t CT, PV, TP, PR;      // [T-1][G][{4,64,128,VP}][16]  (TP: stack top rows, then one-hot rows of the fed token)
   size_t DG[PMG_MAX_LAYERS];  // [T-1][G][4H][16]
   size_t DX;                  // [T][G][NXT*16][16]
   size_t DS;                  // [2][G][SW]

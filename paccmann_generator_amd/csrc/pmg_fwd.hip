@@ -682,7 +682,7 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
         if (st_d0 == 0) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) xtop[(4 * st_bq + j) * PMG_XTP + st_w] = nw[j];
-          if (keep) st4(a.TP + ((size_t)i * G + g) * 1024 + st_w * 16 + 4 * st_bq, nw);
+          if (keep) st4(a.TP + ((size_t)i * G + g) * 2048 + st_w * 16 + 4 * st_bq, nw);
         }
       }
       stk.s_prev = c0;
@@ -728,6 +728,16 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
     }
 
     // ------------------------------------------------------------ layer 0: stack-top GEMM, table, gates
+    if (keep && tid < 256) {
+      // one-hot rows of the token fed at this step, behind the stack-top rows of the same slab: the
+      // B operand [stack top | one-hot(token)] of the weight-gradient job that yields dW_ih[0][:, E:]
+      // and the per-token gate-table gradient in one pass (vocabularies of at most 64 tokens)
+      const int v = tid >> 2, sq = tid & 3;
+      f32x4 oh;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) oh[j] = (row0 + 4 * sq + j < B && misc[4 * sq + j] == v) ? 1.0f : 0.0f;
+      pmg_st4h<1>(a.TP + ((size_t)i * G + g) * 2048 + (64 + v) * 16 + 4 * sq, oh);
+    }
     f32x4 bhn[UPW];
 #pragma unroll
     for (int u = 0; u < UPW; ++u) {

@@ -13,6 +13,9 @@
 //   IH[l]  dW_ih[l>0]    = [dr|dz|dn]^T    h^{l-1}_p
 //   IS     dW_ih[0][:,E:]= [dr|dz|dn]^T    stack_top_p
 //   TAB    dGTAB         = [dr|dz|dn]^T    onehot(tok_p)   -> embedding, W_ih[0][:, :E]
+//          (vocabularies of at most 64 tokens: IS and TAB are ONE plain job, the forward having left
+//          [stack top | one-hot(tok)] as one 128-row slab; larger ones: TAB is a job of its own whose B
+//          operand is generated from the token ids)
 //   X      d[W_ctrl;W_push;W_out] = [dctrl_p|dpush_p|dlogits_{p-1}]^T h^{top}_{p-1}
 // Bias gradients are the row sums of the A operands.
 // Split-K over slabs into per-split partial tiles, then a deterministic reduce and a
@@ -25,13 +28,11 @@
 #define WG_MAXJOBS (2 + 2 * PMG_MAX_LAYERS + 1)
 #define WG_PLAIN 0
 #define WG_ONEHOT 1
-#define WG_MIXED 2
 
 struct WJob {
   const float* A;   // slabs [P][G][a_rows][16]
   const float* B;   // slabs [P(+shift)][G][b_rows][16]  (unused when mode == WG_ONEHOT)
-  int mode;         // WG_PLAIN, WG_ONEHOT (B = one-hot of the tokens) or WG_MIXED (columns 0..63 from B,
-                    // columns 64..127 one-hot of the tokens: the stack-top and embedding-table jobs share A)
+  int mode;         // WG_PLAIN or WG_ONEHOT (B = one-hot of the tokens, generated in the kernel)
   int a_rows;       // rows of one A slab
   int skip_mid;     // 1: job row r >= 2H maps to slab row r + H (dgh: skip the dn piece)
   int b_rows;       // rows of one B slab
@@ -69,7 +70,6 @@ namespace {
 // byte offset per fragment); two register sets keep the next slab in flight.
 template <int MI, int NJ, int WR, int WC, int MODE>
 __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArgs a) {
-  static_assert(MODE != WG_MIXED || (WC == 2 && NJ == 4), "mixed tiles: one wave column per half");
   constexpr int TN = 16 * NJ * WC;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -124,12 +124,11 @@ __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArg
   for (int j = 0; j < NJ; ++j) {
     int cc = c0 + 16 * j;
     if (cc >= jb.cols) cc = 0;
-    if (MODE == WG_MIXED) cc &= 63;  // the one-hot half never loads; keep its offsets in range
     brow[j] = (unsigned)cc * 64u;
   }
   // one-hot columns: token id that column n16 of fragment j stands for
-  const bool onehot = (MODE == WG_ONEHOT) || (MODE == WG_MIXED && wc == 1);
-  const int oh0 = (MODE == WG_MIXED) ? 0 : c0;
+  constexpr bool onehot = (MODE == WG_ONEHOT);
+  const int oh0 = c0;
   const unsigned voff = (unsigned)(n16 * 16 + 4 * q) * 4u;
   const unsigned astr = (unsigned)jb.a_rows * 64u, bstr = (unsigned)jb.b_rows * 64u;
   const int nsafe = ns > 0 ? ns : 0;
@@ -433,10 +432,12 @@ void build_plan(const PmgDims& d, JobPlan* P) {
   for (int l = 0; l < d.L; ++l) { WJob& j = add(3 * H, H, 4 * H, 1, H, 0, N, WG_PLAIN); f.c_hh[l] = j.c_off; f.rs_hh[l] = j.rs0; }
   // layer 0: the stack-top columns of W_ih and the per-token gate table share their A operand
   // ([dr|dz|dn]); with a vocabulary of at most 64 they are the two halves of one 128-wide tile column
+  // whose B operand is the forward's [stack top | one-hot(token)] slab
   const bool mixed = d.VP <= 64;
   for (int l = 0; l < d.L; ++l) {
-    WJob& j = (l == 0) ? (mixed ? add(3 * H, 128, 4 * H, 0, PMG_KS, 0, N, WG_MIXED)
-                                : add(3 * H, PMG_KS, 4 * H, 0, PMG_KS, 0, N, WG_PLAIN))
+    // the TP slab holds [64 stack-top rows | 64 one-hot rows of the fed token] (written by the forward)
+    WJob& j = (l == 0) ? (mixed ? add(3 * H, 128, 4 * H, 0, 128, 0, N, WG_PLAIN)
+                                : add(3 * H, PMG_KS, 4 * H, 0, 128, 0, N, WG_PLAIN))
                        : add(3 * H, H, 4 * H, 0, H, 1, N, WG_PLAIN);
     f.c_ih[l] = j.c_off; f.rs_gi[l] = j.rs0;
   }
@@ -449,11 +450,11 @@ void build_plan(const PmgDims& d, JobPlan* P) {
   { WJob& j = add(d.NXT * 16, H, d.NXT * 16, 0, H, 0, N + 1, WG_PLAIN); f.c_x = j.c_off; f.rs_x = j.rs0; }
   w.njobs = nj; w.tiles_wide = tile_w; w.tiles_narrow = tile_n; w.total_rs = rs;
   {
-    int cnt[2][3] = {{0, 0, 0}, {0, 0, 0}}, Sl[2][3];
+    int cnt[2][2] = {{0, 0}, {0, 0}}, Sl[2][2];
     for (int j = 0; j < nj; ++j) cnt[w.jobs[j].tn == 128][w.jobs[j].mode] += w.jobs[j].row_tiles * w.jobs[j].col_tiles;
     w.S = 1;
     for (int a2 = 0; a2 < 2; ++a2)
-      for (int m = 0; m < 3; ++m) {
+      for (int m = 0; m < 2; ++m) {
         Sl[a2][m] = cnt[a2][m] ? choose_splits(d, cnt[a2][m]) : 1;
         if (Sl[a2][m] > w.S) w.S = Sl[a2][m];
       }
@@ -505,7 +506,9 @@ hipError_t pmg_run_wgrad(const PmgDims& d, const PmgLayout& lay, float* ws, cons
   w.jobs[k].A = ws + lay.DX; w.jobs[k].B = ws + lay.HH[d.L - 1]; ++k;
 
   hipError_t e = hipSuccess;
-  {
+  bool need_tok32 = false;
+  for (int j = 0; j < w.njobs; ++j) need_tok32 = need_tok32 || w.jobs[j].mode == WG_ONEHOT;
+  if (need_tok32) {
     const size_t total = (size_t)(d.T - 1) * d.G * 16;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -514,7 +517,7 @@ hipError_t pmg_run_wgrad(const PmgDims& d, const PmgLayout& lay, float* ws, cons
     if (e != hipSuccess) return e;
   }
   {
-    int nt[2][3] = {{0, 0, 0}, {0, 0, 0}};  // [wide][mode]
+    int nt[2][2] = {{0, 0}, {0, 0}};  // [wide][mode]
     for (int j = 0; j < w.njobs; ++j)
       nt[w.jobs[j].tn == 128][w.jobs[j].mode] += w.jobs[j].row_tiles * w.jobs[j].col_tiles;
 #define PMG_WG_LAUNCH(wide_, mode_, ...)                                                     \
@@ -528,7 +531,6 @@ hipError_t pmg_run_wgrad(const PmgDims& d, const PmgLayout& lay, float* ws, cons
     if (e != hipSuccess) return e;                                                           \
   }
     PMG_WG_LAUNCH(1, WG_PLAIN, 4, 4, 2, 2, WG_PLAIN)
-    PMG_WG_LAUNCH(1, WG_MIXED, 4, 4, 2, 2, WG_MIXED)
     PMG_WG_LAUNCH(1, WG_ONEHOT, 4, 4, 2, 2, WG_ONEHOT)
     PMG_WG_LAUNCH(0, WG_PLAIN, 2, 4, 4, 1, WG_PLAIN)
     PMG_WG_LAUNCH(0, WG_ONEHOT, 2, 4, 4, 1, WG_ONEHOT)
