@@ -216,6 +216,12 @@ def time_phases(learner, cfg, latent, rewards, B, reps=3):
     return out
 
 
+def rank_command(n_gpus: int, argv, port: int):
+    """Command line that starts the N ranks of `bench.py --gpus N` (one process per GPU on one node)."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_gpus}',
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -245,9 +251,7 @@ def main():
         with socket.socket() as sk:
             sk.bind(('127.0.0.1', 0))
             port = sk.getsockname()[1]
-        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
-               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd))
+        raise SystemExit(subprocess.call(rank_command(args.gpus, sys.argv[1:], port)))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
