@@ -351,6 +351,10 @@ def main():
                    'batch_per_gpu': B, 'global_batch': B * world, 'len': T, 'parallelism': f'dp{world}',
                    'flop_per_token_fwd': F},
         'step_roofline_frac': (tokens_per_s / world) * 3 * F / (PEAK_F32_MFMA_TFLOPS * 1e12),
+        # the teacher-forced re-forward the reference performs is executed but not
+        # counted in the 3F figure above; this is the executed (4F) figure alongside (cfg5 executes 3F)
+        'step_executed_flop_frac': (tokens_per_s / world) * (3 if args.config == 'cfg5' else 4) * F /
+                                   (PEAK_F32_MFMA_TFLOPS * 1e12),
         'tokens_per_step_per_gpu': tokens_per_step,
     }
     if rank == 0:
