@@ -403,7 +403,8 @@ def _reinforce_backward(ctx, g_loss, g_logp, g_gh0, g_grads):
         raise RuntimeError('pmg::reinforce_loss was called with with_grads=False: no gradient was formed')
     grad_h0, *grads = ctx.saved_tensors
     gl = g_loss.to(torch.float32)
-    return (None, (grad_h0 * gl).to(ctx.h0_dtype), None, None, [g * gl for g in grads], None, None, None, None)
+    scaled = list(torch._foreach_mul(grads, gl)) if grads else []      # one multi-tensor launch, not 4L+7
+    return (None, (grad_h0 * gl).to(ctx.h0_dtype), None, None, scaled, None, None, None, None)
 
 
 _reinforce_loss_op.register_autograd(_reinforce_backward, setup_context=_reinforce_setup)
