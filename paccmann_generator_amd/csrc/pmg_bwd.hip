@@ -31,6 +31,28 @@
 #define PMG_BWD_AUX_DG 0
 #endif
 
+// Helper waves (H = 512): four extra waves per workgroup, one per SIMD, that never touch the weight
+// stream.  They take everything of a step that is not on the recurrent chain -- gate-gradient slab
+// stores (from the LDS chunk buffers), the stack backward of rows >= 2, dlogits, the DX slab -- and
+// run it under the products of the eight MFMA waves; only rows 0/1 of the stack backward (they need
+// this step's dtop) and the control gradients stay between the products and the extras product.
+// A wave's vector-memory operations return in order, which is why the same work as a side job of
+// the MFMA waves themselves lost (profiles/r02_experiments.md): a helper's slow loads only delay
+// the helper.
+#ifndef PMG_BWD_HELP
+#define PMG_BWD_HELP 1
+#endif
+#define PMG_HELP_THREADS 256
+#ifndef PMG_HELP_PRIO
+#define PMG_HELP_PRIO 3
+#endif
+#ifndef PMG_HELP_X
+#define PMG_HELP_X 0
+#endif
+#ifndef PMG_HBLK
+#define PMG_HBLK 4      // stack rows per load burst of a helper thread
+#endif
+
 namespace {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) {
@@ -48,6 +70,14 @@ template <int AUX> __device__ __forceinline__ f32x4 bl4a(__amdgpu_buffer_rsrc_t 
   const pmg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
   f32x4 o; o.x = __uint_as_float(v.x); o.y = __uint_as_float(v.y); o.z = __uint_as_float(v.z); o.w = __uint_as_float(v.w);
   return o;
+}
+
+// buffer resource from values the compiler cannot prove wave-uniform by itself (they are): pinned
+// to SGPRs so that the accesses are not wrapped in waterfall loops
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_uniform(const float* base, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return pmg_rsrc(reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo), __builtin_amdgcn_readfirstlane(bytes));
 }
 
 // acc[t] += Wt[tile t][24 groups per chunk] * chunk columns.  24 reduction groups per chunk: 8 per
@@ -154,8 +184,8 @@ __device__ __forceinline__ void gemm_lin(f32x4 (&acc)[NT], const __amdgpu_buffer
 
 // MULTI: more than one GRU layer (only then is the W_ih^T product of a layer carried to the layer
 // below; a single-layer kernel does not hold those accumulators).
-template <int UPW, bool MULTI>
-__global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a) {
+template <int UPW, bool MULTI, bool HELP>
+__global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS, HELP ? 3 : 2) void pmg_bwd_kernel(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int H = a.H, XP = a.XP, W = a.W, D = a.D, V = a.V, L = a.L, B = a.B, G = a.G, N = a.N;
   const int UT = H / 16, NXT = a.NXT;
@@ -176,19 +206,30 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
   const __amdgpu_buffer_rsrc_t wrs = pmg_rsrc(a.wbase, a.wbytes);
   const unsigned voff = (unsigned)lane * 16u;
 
+  constexpr int NTHR = HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS;
+  const bool helper = HELP && wave >= PMG_WAVES;  // wave-uniform
+#if PMG_HELP_PRIO
+  // a helper shares its SIMD with two MFMA waves that always have an instruction ready; without
+  // priority its few VALU / LDS / memory instructions wait for gaps in their issue
+  if (helper) __builtin_amdgcn_s_setprio(PMG_HELP_PRIO);
+#endif
+  const int ht = tid - PMG_THREADS;               // helper thread index
+  const int lt = HELP ? ht : tid;                 // index among the threads that own the per-row scalars
+
   float* dhc = a.DHC + (size_t)g * L * H * 16;
   // zero the carry (own elements only: each lane re-reads exactly what it wrote)
-  for (int l = 0; l < L; ++l)
+  if (!helper)
+    for (int l = 0; l < L; ++l)
 #pragma unroll
-    for (int u = 0; u < UPW; ++u) {
-      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-      st4(dhc + ((size_t)(l * UT + wave * UPW + u)) * 256 + lane * 4, z4);
-    }
-  for (int idx = tid; idx < 16 * XP; idx += PMG_THREADS) dxl[idx] = 0.0f;
-  for (int idx = tid; idx < 16 * PMG_XTP; idx += PMG_THREADS) dtl[idx] = 0.0f;
-  float lossacc = 0.0f;  // threads 0..15: sum_p R_b * logp[p][b]
+      for (int u = 0; u < UPW; ++u) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        st4(dhc + ((size_t)(l * UT + wave * UPW + u)) * 256 + lane * 4, z4);
+      }
+  for (int idx = tid; idx < 16 * XP; idx += NTHR) dxl[idx] = 0.0f;
+  for (int idx = tid; idx < 16 * PMG_XTP; idx += NTHR) dtl[idx] = 0.0f;
+  float lossacc = 0.0f;  // threads lt = 0..15: sum_p R_b * logp[p][b]
   float myR = 0.0f;
-  if (tid < 16) myR = (row0 + tid < B) ? a.reward[row0 + tid] : 0.0f;
+  if (lt >= 0 && lt < 16) myR = (row0 + lt < B) ? a.reward[row0 + lt] : 0.0f;
   const float rowR = (row0 + (tid & 15) < B) ? a.reward[row0 + (tid & 15)] : 0.0f;  // reward of row tid&15
   __syncthreads();
 
@@ -206,6 +247,223 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
   // p == N is the virtual step that only injects dlogits_{N-1}
   for (int p = N; p >= 0; --p) {
     const bool virt = (p == N);
+    if (HELP && helper) {
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      const int hb = ht & 15;
+      // ---- dlogits_{p-1} and the loss terms: nothing recurrent
+      {
+        const int dl_row = row0 + hb;
+        int y = 0;
+        if (p >= 1 && dl_row < B) y = (int)a.tokens[(size_t)p * B + dl_row];
+        float pr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float* prp = a.PR + (((size_t)(p > 0 ? p - 1 : 0) * G + g) * a.VP) * 16 + hb;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int v = (ht >> 4) + 16 * k;
+          if (p >= 1 && v < V) pr[k] = pmg_ld1h<4>(prp + (size_t)v * 16);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int v = (ht >> 4) + 16 * k;
+          if (v < V) dxl[hb * XP + 3 + W + v] = (p >= 1) ? a.scale * rowR * (pr[k] - ((v == y) ? 1.0f : 0.0f)) : 0.0f;
+        }
+        for (int v = (ht >> 4) + 64; v < V; v += PMG_HELP_THREADS / 16) {  // V > 64
+          float val = 0.0f;
+          if (p >= 1) val = a.scale * rowR * (pmg_ld1h<4>(prp + (size_t)v * 16) - ((v == y) ? 1.0f : 0.0f));
+          dxl[hb * XP + 3 + W + v] = val;
+        }
+        if (p >= 1 && ht < 16) lossacc += myR * a.LP[((size_t)(p - 1) * G + g) * 16 + ht];
+      }
+      PMG_TICK(0)
+      float ct_h[3] = {0.0f, 0.0f, 0.0f};
+      if (!virt && ht < 16) {
+        const float* ct = a.CT + ((size_t)p * G + g) * 64;
+        ct_h[0] = ct[ht]; ct_h[1] = ct[16 + ht]; ct_h[2] = ct[32 + ht];
+      }
+      // ---- stack backward, part 1: what does not need this step's dtop.  Thread ht owns column
+      // (w = ht >> 2, sequences 4*(ht & 3)..+3) over all rows, so every gradient row it reads was
+      // written by itself one step earlier.
+      // (threads past the last column run the same code on offsets outside every buffer: they read
+      // zeros and their stores are dropped, so the control flow below is uniform)
+      const int sbq = ht & 3, sw = ht >> 2;
+      const bool scol = !virt && sw < W;
+      const int swc = sw < W ? sw : W - 1;
+      f32x4 sn = zero4, sp = zero4, sq = zero4;
+      f32x4 apush = zero4, apop = zero4, anoop = zero4, pv = zero4;
+      f32x4 g0in = zero4, g1 = zero4, g2 = zero4, s0 = zero4, s1 = zero4;
+      int nrows = 0;
+      float* dSout = a.DS + ((size_t)(p & 1) * G + g) * a.SW;
+      if (!virt) {
+        const float* ctp = a.CT + ((size_t)p * G + g) * 64 + 4 * sbq;
+        apush = ld4(ctp); apop = ld4(ctp + 16); anoop = ld4(ctp + 32);
+        pv = ld4(a.PV + ((size_t)p * G + g) * 1024 + swc * 16 + 4 * sbq);
+      }
+      if (!virt) {
+        for (int l = L - 1; l >= 0; --l) {
+          const __amdgpu_buffer_rsrc_t dgr = pmg_rsrc(a.DG[l] + (((size_t)p * G + g) * 4 * H) * 16, (unsigned)H * 256u);
+#pragma unroll
+          for (int rd = 0; rd < UPW / NCB; ++rd) {
+            if (rd > 0 || (MULTI && l < L - 1)) __syncthreads();  // mirrors the MFMA waves
+            __syncthreads();                                       // chunk buffers of this round filled
+            // gate-gradient row slabs [gate row][16 sequences] out of the chunk buffers
+            // ([sequence][piece*128 + column]): 4 x ds_read_b32 + one 16-byte store, 1 KB contiguous per wave
+            const int x0 = ht >> 2;
+            const float* src0 = cb + (size_t)(4 * sbq) * PMG_CP + x0;
+            const unsigned vo0 = (unsigned)(16 * ((x0 >> 4) * UPW) + (x0 & 15)) * 64u + (unsigned)sbq * 16u;
+            const unsigned vo1 = vo0 + (unsigned)(16 * 4 * UPW) * 64u;   // column x0 + 64: four waves further
+#pragma unroll
+            for (int i = 0; i < NCB * 8; ++i) {
+              const int hi = i & 1, gate = (i >> 1) & 3, cc = i >> 3;
+              const float* src = src0 + (size_t)cc * 16 * PMG_CP + gate * PMG_CHUNK + 64 * hi;
+              pmg_u32x4 u;
+              u.x = __float_as_uint(src[0]); u.y = __float_as_uint(src[PMG_CP]);
+              u.z = __float_as_uint(src[2 * PMG_CP]); u.w = __float_as_uint(src[3 * PMG_CP]);
+              __builtin_amdgcn_raw_buffer_store_b128(u, dgr, hi ? vo1 : vo0,
+                                                     (unsigned)(rd * NCB + cc) * 1024u + (unsigned)gate * (unsigned)H * 64u,
+                                                     PMG_BWD_AUX_DG);
+            }
+          }
+        }
+      }
+      PMG_TICK(1)
+      // Rows outside the live ranges (see the forward) read as zero through the bounds of the buffer
+      // resources instead of per-element selects, addresses are one lane-constant offset plus scalar
+      // row offsets, and the burst is unrolled so that the row window (previous / this / next) is
+      // renamed, not moved: a helper shares its SIMD's ALUs with two waves of fp32 MFMAs, and every
+      // vector instruction it issues is time taken from them.
+      const unsigned rs4 = (unsigned)W * 64u;            // bytes per stack row of 16 sequences
+      const unsigned cvo = sw < W ? (unsigned)(sw * 16 + 4 * sbq) * 4u : 0x40000000u;
+      const __amdgpu_buffer_rsrc_t ors = rsrc_uniform(dSout, (unsigned)D * rs4);
+      if (!virt) {
+        const int mn = (p < N - p) ? p : N - p;
+        nrows = (mn > D - 1) ? D : mn + 1;
+        const int s_lim = (p - 1 < N - p) ? p - 1 : N - p;
+        const int g_lim = (p < N - 1 - p) ? p : N - 1 - p;
+        const int s_hi = s_lim < D - 1 ? s_lim : D - 1;
+        const int g_hi = g_lim < D - 1 ? g_lim : D - 1;
+#if PMG_HELP_X == 1
+        const float* Sprev = a.SB + ((size_t)0 * G + g) * a.SW;   // experiment: cache-resident rows (wrong results)
+#else
+        const float* Sprev = a.SB + ((size_t)p * G + g) * a.SW;
+#endif
+        const float* dSin = a.DS + ((size_t)((p + 1) & 1) * G + g) * a.SW;
+        const __amdgpu_buffer_rsrc_t srs = rsrc_uniform(Sprev, (p == 0 || s_hi < 0) ? 0u : (unsigned)(s_hi + 1) * rs4);
+        const __amdgpu_buffer_rsrc_t grs = rsrc_uniform(dSin, (p == N - 1 || g_hi < 0) ? 0u : (unsigned)(g_hi + 1) * rs4);
+#if PMG_HELP_X == 2
+        nrows = nrows < 1 ? nrows : 1;                            // experiment: no part 1 (wrong results)
+#endif
+        // (only the per-lane offset of a buffer access is checked against the bounds, so the row
+        // offsets go there: one add per row)
+        constexpr int SAUX = (PMG_NT & 4) ? 2 : 0;
+        const unsigned v1 = cvo + rs4, v2 = v1 + rs4;
+        g0in = bl4(grs, cvo, 0u); g1 = bl4(grs, v1, 0u); g2 = bl4(grs, v2, 0u);
+        s0 = bl4a<SAUX>(srs, cvo, 0u); s1 = bl4a<SAUX>(srs, v1, 0u);
+        const f32x4 s2 = bl4a<SAUX>(srs, v2, 0u);
+        if (nrows >= 2) {   // row 1: sums now, its gradient row once dtop is there
+          sn += g1 * s1;
+          sp += g1 * s0;
+          sq += g1 * s2;
+        }
+        f32x4 gm = g1, gc = g2, sm = s1, sc = s2;
+        const int nb = (nrows - 2 + PMG_HBLK - 1) / PMG_HBLK;     // bursts covering rows 2 .. nrows-1
+        unsigned vr = v2;                                          // first row of the burst
+        for (int it = 0; it < nb; ++it) {
+          f32x4 gv[PMG_HBLK], sv[PMG_HBLK];
+          unsigned vo[PMG_HBLK + 1];
+          vo[0] = vr;
+#pragma unroll
+          for (int k = 0; k < PMG_HBLK; ++k) {
+            vo[k + 1] = vo[k] + rs4;
+            gv[k] = bl4(grs, vo[k + 1], 0u);
+            sv[k] = bl4a<SAUX>(srs, vo[k + 1], 0u);
+          }
+#pragma unroll
+          for (int k = 0; k < PMG_HBLK; ++k) {
+            // row r = 2 + it*PMG_HBLK + k; rows >= nrows have a zero gradient (bounds), and their
+            // stores land in rows nobody reads or beyond the slab (dropped)
+            sn += gc * sc;
+            sp += gc * sm;
+            sq += gc * sv[k];
+            const f32x4 dprev = anoop * gc + apush * gv[k] + apop * gm;
+            pmg_u32x4 u;
+            u.x = __float_as_uint(dprev[0]); u.y = __float_as_uint(dprev[1]); u.z = __float_as_uint(dprev[2]); u.w = __float_as_uint(dprev[3]);
+            __builtin_amdgcn_raw_buffer_store_b128(u, ors, vo[k], 0u, 0);
+            gm = gc; gc = gv[k]; sm = sc; sc = sv[k];
+          }
+          vr = vo[PMG_HBLK];
+        }
+      }
+      PMG_TICK(2)
+      if (!virt) {
+        __syncthreads();  // dtop visible
+        PMG_TICK(3)
+        // ---- stack backward, part 2: rows 0 and 1
+        if (scol) {
+          f32x4 g0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) g0[j] = g0in[j] + dtl[(4 * sbq + j) * PMG_XTP + sw];
+          sn += g0 * s0;
+          sp += g0 * pv;
+          sq += g0 * s1;
+          {
+            const f32x4 d0 = anoop * g0 + apush * g1, d1 = anoop * g1 + apush * g2 + apop * g0;
+            pmg_u32x4 u0, u1;
+            u0.x = __float_as_uint(d0[0]); u0.y = __float_as_uint(d0[1]); u0.z = __float_as_uint(d0[2]); u0.w = __float_as_uint(d0[3]);
+            u1.x = __float_as_uint(d1[0]); u1.y = __float_as_uint(d1[1]); u1.z = __float_as_uint(d1[2]); u1.w = __float_as_uint(d1[3]);
+            __builtin_amdgcn_raw_buffer_store_b128(u0, ors, cvo, 0u, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u1, ors, nrows >= 2 ? cvo + rs4 : 0xfffffff0u, 0u, 0);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dxl[(4 * sbq + j) * XP + 3 + sw] = apush[j] * g0[j] * (1.0f - pv[j] * pv[j]);
+        }
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            sn[j] += __shfl_xor(sn[j], o);
+            sp[j] += __shfl_xor(sp[j], o);
+            sq[j] += __shfl_xor(sq[j], o);
+          }
+        }
+        if (lane < 4) {
+          float* rp = red + ((wave - PMG_WAVES) * 4 + lane) * 12;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { rp[j] = sp[j]; rp[4 + j] = sq[j]; rp[8 + j] = sn[j]; }
+        }
+      }
+      PMG_TICK(4)
+      __syncthreads();
+      if (!virt && ht < 16) {
+        const int bq = ht >> 2, j = ht & 3;
+        float dpu = 0.f, dpo = 0.f, dno = 0.f;
+        for (int wv = 0; wv < PMG_HELP_THREADS / 64; ++wv) {
+          const float* rp = red + (wv * 4 + bq) * 12;
+          dpu += rp[j]; dpo += rp[4 + j]; dno += rp[8 + j];
+        }
+        const float a0 = ct_h[0], a1 = ct_h[1], a2 = ct_h[2];
+        const float s = a0 * dpu + a1 * dpo + a2 * dno;
+        dxl[ht * XP + 0] = a0 * (dpu - s);
+        dxl[ht * XP + 1] = a1 * (dpo - s);
+        dxl[ht * XP + 2] = a2 * (dno - s);
+      }
+      __syncthreads();
+      PMG_TICK(5)
+      {
+        // DX slab [extras row][16 sequences] for the weight-gradient GEMM, next to the extras product
+        float* dxg = a.DX + ((size_t)p * G + g) * NXT * 256;
+        for (int i4 = ht; i4 < NXT * 64; i4 += PMG_HELP_THREADS) {
+          const int nrow = i4 >> 2, bq = i4 & 3;
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = dxl[(4 * bq + j) * XP + nrow];
+          pmg_st4h<8>(dxg + nrow * 16 + 4 * bq, v);
+        }
+      }
+      PMG_TICK(6)
+      __syncthreads();  // dxl / dtl / red reusable
+      PMG_TICK(7)
+      continue;
+    }
     // dlogits_{p-1} inputs (probabilities, target token; nothing recurrent) are requested here, one
     // step's worth of products before they are used, so their latency is off the serial chain.
     // Thread tid covers row tid&15 and vocabulary entries tid>>4 and 32 + (tid>>4); larger
@@ -213,7 +471,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
     const int dl_row = row0 + (tid & 15);
     int dl_y = 0;
     float dl_pr[2] = {0.0f, 0.0f};
-    if (p >= 1) {
+    if (!HELP && p >= 1) {
       dl_y = (dl_row < B) ? (int)a.tokens[(size_t)p * B + dl_row] : 0;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -222,7 +480,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
       }
     }
     float ct_a[3] = {0.0f, 0.0f, 0.0f};  // stack controls of row tid (threads 0..15), same early request
-    if (!virt && tid < 16) {
+    if (!HELP && !virt && tid < 16) {
       const float* ct = a.CT + ((size_t)p * G + g) * 64;
       ct_a[0] = ct[tid]; ct_a[1] = ct[16 + tid]; ct_a[2] = ct[32 + tid];
     }
@@ -284,7 +542,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
             float* cbw = cb + (size_t)cc * 16 * PMG_CP + b * PMG_CP + 16 * wave + 4 * q;
             st4(cbw, dr_pre); st4(cbw + PMG_CHUNK, dz_pre); st4(cbw + 2 * PMG_CHUNK, dn_pre);
             st4(cbw + 3 * PMG_CHUNK, dghn);
-            if (!(dbg & 0x1000))
+            if (!HELP && !(dbg & 0x1000))
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const unsigned so = ((unsigned)c * 256u + j * 16u) * 4u, gH = (unsigned)H * 64u;
@@ -328,7 +586,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
     }
 
     // ------------------------------------------------------------ stack backward
-    if (!virt && !(dbg & 0x100)) {
+    if (!HELP && !virt && !(dbg & 0x100)) {
       // Live rows (see the forward): S_{p-1} holds data in rows <= min(p-1, N-p), the incoming
       // gradient (w.r.t. S_p) in rows <= min(p, N-1-p); gradients of rows that are constant zero
       // or can no longer reach a stack top are neither needed nor formed.
@@ -429,7 +687,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
     }
     PMG_TICK(4)
     // ------------------------------------------------------------ dlogits_{p-1}, loss
-    {
+    if (!HELP) {
       const float sc = a.scale;
       const int bb = tid & 15;
 #pragma unroll
@@ -449,7 +707,7 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
       if (p >= 1 && tid < 16) lossacc += myR * a.LP[((size_t)(p - 1) * G + g) * 16 + tid];
     }
     __syncthreads();
-    if (!virt && tid < 16) {
+    if (!HELP && !virt && tid < 16) {
       const int bq = tid >> 2, j = tid & 3;
       float dpu = 0.f, dpo = 0.f, dno = 0.f;
       for (int wv = 0; wv < PMG_WAVES; ++wv) {
@@ -466,10 +724,12 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
     PMG_TICK(5)
     // ------------------------------------------------------------ DX slab + extras product
     {
-      float* dxg = a.DX + ((size_t)p * G + g) * NXT * 256;
-      for (int idx = tid; idx < NXT * 256; idx += PMG_THREADS) {
-        const int bb = idx & 15, nrow = idx >> 4;
-        pmg_st1h<8>(dxg + idx, dxl[bb * XP + nrow]);
+      if (!HELP) {
+        float* dxg = a.DX + ((size_t)p * G + g) * NXT * 256;
+        for (int idx = tid; idx < NXT * 256; idx += PMG_THREADS) {
+          const int bb = idx & 15, nrow = idx >> 4;
+          pmg_st1h<8>(dxg + idx, dxl[bb * XP + nrow]);
+        }
       }
       f32x4 acc[UPW];
 #pragma unroll
@@ -490,14 +750,15 @@ __global__ __launch_bounds__(PMG_THREADS, 2) void pmg_bwd_kernel(const BwdArgs a
 #endif
 
   // ---------------------------------------------------------------- outputs
-  for (int l = 0; l < L; ++l)
+  if (!helper)
+    for (int l = 0; l < L; ++l)
 #pragma unroll
-    for (int u = 0; u < UPW; ++u) {
-      const f32x4 v = ld4(dhc + ((size_t)(l * UT + wave * UPW + u)) * 256 + lane * 4);
-      const int row = row0 + b;
-      if (row < B) st4(a.grad_h0 + ((size_t)l * B + row) * H + 16 * (wave * UPW + u) + 4 * q, v);
-    }
-  if (tid < 16) lsl[tid] = lossacc;
+      for (int u = 0; u < UPW; ++u) {
+        const f32x4 v = ld4(dhc + ((size_t)(l * UT + wave * UPW + u)) * 256 + lane * 4);
+        const int row = row0 + b;
+        if (row < B) st4(a.grad_h0 + ((size_t)l * B + row) * H + 16 * (wave * UPW + u) + 4 * q, v);
+      }
+  if (lt >= 0 && lt < 16) lsl[lt] = lossacc;
   __syncthreads();
   if (tid == 0) {
     float s = 0.0f;
@@ -513,14 +774,14 @@ size_t pmg_bwd_lds_bytes(const BwdArgs* a) {
   return (ncb * 16 * PMG_CP + (size_t)16 * a->XP + 16 * PMG_XTP + PMG_WAVES * 48 + 16) * sizeof(float);
 }
 
-template <int UPW, bool MULTI>
+template <int UPW, bool MULTI, bool HELP = false>
 static hipError_t launch_bwd_t(const BwdArgs* a, hipStream_t st) {
   const size_t lds = pmg_bwd_lds_bytes(a);
-  auto kern = pmg_bwd_kernel<UPW, MULTI>;
+  auto kern = pmg_bwd_kernel<UPW, MULTI, HELP>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(a->G), dim3(PMG_THREADS), lds, st, *a);
+  hipLaunchKernelGGL(kern, dim3(a->G), dim3(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS), lds, st, *a);
   return hipGetLastError();
 }
 
@@ -529,7 +790,7 @@ hipError_t pmg_launch_bwd(const BwdArgs* a, hipStream_t st) {
   switch (a->H) {
     case 128: return m ? launch_bwd_t<1, true>(a, st) : launch_bwd_t<1, false>(a, st);
     case 256: return m ? launch_bwd_t<2, true>(a, st) : launch_bwd_t<2, false>(a, st);
-    case 512: return m ? launch_bwd_t<4, true>(a, st) : launch_bwd_t<4, false>(a, st);
+    case 512: return m ? launch_bwd_t<4, true, PMG_BWD_HELP != 0>(a, st) : launch_bwd_t<4, false, PMG_BWD_HELP != 0>(a, st);
     case 1024: return m ? launch_bwd_t<8, true>(a, st) : launch_bwd_t<8, false>(a, st);
   }
   return hipErrorInvalidValue;
