@@ -167,9 +167,10 @@ __device__ __forceinline__ void gemm_chunks(f32x4 (&acc)[NT], const __amdgpu_buf
 // acc[t] += Wt[tile t][0..KG) * x[b][0..16*KG)   (plain contiguous reduction)
 template <int NT>
 __device__ __forceinline__ void gemm_lin(f32x4 (&acc)[NT], const __amdgpu_buffer_rsrc_t rs, const unsigned voff,
-                                         const unsigned soff, const unsigned ts, const float* xrow, const int KG) {
+                                         const unsigned soff, const unsigned ts, const float* xrow, const int kg0,
+                                         const int kg1) {
 #pragma unroll 2
-  for (int kg = 0; kg < KG; ++kg) {
+  for (int kg = kg0; kg < kg1; ++kg) {
     const float4 x = *reinterpret_cast<const float4*>(xrow + 16 * kg);
     float4 wc[NT];
 #pragma unroll
@@ -217,8 +218,15 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
   const int lt = HELP ? ht : tid;                 // index among the threads that own the per-row scalars
 
   float* dhc = a.DHC + (size_t)g * L * H * 16;
-  // zero the carry (own elements only: each lane re-reads exactly what it wrote)
-  if (!helper)
+  // One layer: the hidden-gradient carry never leaves the registers of the MFMA waves.  More
+  // layers: it goes through a global slab (own elements only: each lane re-reads what it wrote).
+  f32x4 car[UPW];
+#pragma unroll
+  for (int u = 0; u < UPW; ++u) car[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // extras groups below KX0 hold dctrl / dpush rows (need this step's dtop); the groups from KX0 on
+  // hold only dlogits rows, which are there before the step's products start
+  const int KX0 = (3 + W + 15) / 16;
+  if (MULTI && !helper)
     for (int l = 0; l < L; ++l)
 #pragma unroll
       for (int u = 0; u < UPW; ++u) {
@@ -244,10 +252,13 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
 #define PMG_TICK(k)
 #endif
 
-  // p == N is the virtual step that only injects dlogits_{N-1}
-  for (int p = N; p >= 0; --p) {
+  // p == N is the virtual step that only injects dlogits_{N-1}.  The helper waves run their own
+  // copy of the step loop (same barriers in the same order), so that neither role holds the other's
+  // registers.
+  if (HELP && helper) {
+   for (int p = N; p >= 0; --p) {
     const bool virt = (p == N);
-    if (HELP && helper) {
+    {
       const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
       const int hb = ht & 15;
       // ---- dlogits_{p-1} and the loss terms: nothing recurrent
@@ -290,7 +301,7 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
       const int swc = sw < W ? sw : W - 1;
       f32x4 sn = zero4, sp = zero4, sq = zero4;
       f32x4 apush = zero4, apop = zero4, anoop = zero4, pv = zero4;
-      f32x4 g0in = zero4, g1 = zero4, g2 = zero4, s0 = zero4, s1 = zero4;
+      f32x4 g0in = zero4, g1 = zero4, g2 = zero4, s0 = zero4, s1 = zero4, dS0 = zero4, dS1 = zero4;
       int nrows = 0;
       float* dSout = a.DS + ((size_t)(p & 1) * G + g) * a.SW;
       if (!virt) {
@@ -405,14 +416,8 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
           sn += g0 * s0;
           sp += g0 * pv;
           sq += g0 * s1;
-          {
-            const f32x4 d0 = anoop * g0 + apush * g1, d1 = anoop * g1 + apush * g2 + apop * g0;
-            pmg_u32x4 u0, u1;
-            u0.x = __float_as_uint(d0[0]); u0.y = __float_as_uint(d0[1]); u0.z = __float_as_uint(d0[2]); u0.w = __float_as_uint(d0[3]);
-            u1.x = __float_as_uint(d1[0]); u1.y = __float_as_uint(d1[1]); u1.z = __float_as_uint(d1[2]); u1.w = __float_as_uint(d1[3]);
-            __builtin_amdgcn_raw_buffer_store_b128(u0, ors, cvo, 0u, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(u1, ors, nrows >= 2 ? cvo + rs4 : 0xfffffff0u, 0u, 0);
-          }
+          dS0 = anoop * g0 + apush * g1;
+          dS1 = anoop * g1 + apush * g2 + apop * g0;
 #pragma unroll
           for (int j = 0; j < 4; ++j) dxl[(4 * sbq + j) * XP + 3 + sw] = apush[j] * g0[j] * (1.0f - pv[j] * pv[j]);
         }
@@ -448,6 +453,15 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
       }
       __syncthreads();
       PMG_TICK(5)
+      if (!virt) {
+        // rows 0 and 1 of the stack gradient (kept back so that no store was pending at the two
+        // barriers on the recurrent chain)
+        pmg_u32x4 u0, u1;
+        u0.x = __float_as_uint(dS0[0]); u0.y = __float_as_uint(dS0[1]); u0.z = __float_as_uint(dS0[2]); u0.w = __float_as_uint(dS0[3]);
+        u1.x = __float_as_uint(dS1[0]); u1.y = __float_as_uint(dS1[1]); u1.z = __float_as_uint(dS1[2]); u1.w = __float_as_uint(dS1[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(u0, ors, cvo, 0u, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u1, ors, nrows >= 2 ? cvo + rs4 : 0x40000000u, 0u, 0);
+      }
       {
         // DX slab [extras row][16 sequences] for the weight-gradient GEMM, next to the extras product
         float* dxg = a.DX + ((size_t)p * G + g) * NXT * 256;
@@ -462,8 +476,11 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
       PMG_TICK(6)
       __syncthreads();  // dxl / dtl / red reusable
       PMG_TICK(7)
-      continue;
     }
+   }
+  } else
+  for (int p = N; p >= 0; --p) {
+    const bool virt = (p == N);
     // dlogits_{p-1} inputs (probabilities, target token; nothing recurrent) are requested here, one
     // step's worth of products before they are used, so their latency is off the serial chain.
     // Thread tid covers row tid&15 and vocabulary entries tid>>4 and 32 + (tid>>4); larger
@@ -494,7 +511,7 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
         acc_top[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < UPW; ++u) {
-          dh[u] = ld4(dhc + ((size_t)(l * UT + wave * UPW + u)) * 256 + lane * 4);
+          dh[u] = MULTI ? ld4(dhc + ((size_t)(l * UT + wave * UPW + u)) * 256 + lane * 4) : car[u];
           if (MULTI && l < L - 1) dh[u] += dxa[u];
           acc_hh[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
           acc_dx[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -576,13 +593,23 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
         }
 #pragma unroll
         for (int u = 0; u < UPW; ++u) {
-          st4(dhc + ((size_t)(l * UT + wave * UPW + u)) * 256 + lane * 4, acc_hh[u]);
-          if (MULTI) dxa[u] = acc_dx[u];
+          if (MULTI) {
+            st4(dhc + ((size_t)(l * UT + wave * UPW + u)) * 256 + lane * 4, acc_hh[u]);
+            dxa[u] = acc_dx[u];
+          } else {
+            car[u] = acc_hh[u];
+          }
         }
         if (l == 0 && wave < PMG_KS / 16) st4(dtl + b * PMG_XTP + 16 * wave + 4 * q, acc_top[0]);
       }
       __syncthreads();  // dtop visible; chunk buffers free
       PMG_TICK(3)
+      if (HELP && !MULTI) {
+        // the dlogits part of the extras product, while the helpers finish rows 0/1 of the stack
+        // backward and the control gradients
+        const unsigned so = a.oWXt + (unsigned)(wave * UPW) * (unsigned)NXT * 1024u;
+        if (!(dbg & 0x200)) gemm_lin<UPW>(car, wrs, voff, so, (unsigned)NXT * 1024u, dxl + b * XP + 4 * q, KX0, NXT);
+      }
     }
 
     // ------------------------------------------------------------ stack backward
@@ -731,13 +758,18 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
           pmg_st1h<8>(dxg + idx, dxl[bb * XP + nrow]);
         }
       }
-      f32x4 acc[UPW];
-#pragma unroll
-      for (int u = 0; u < UPW; ++u) acc[u] = ld4(dhc + ((size_t)((L - 1) * UT + wave * UPW + u)) * 256 + lane * 4);
       const unsigned so = a.oWXt + (unsigned)(wave * UPW) * (unsigned)NXT * 1024u;
-      if (!(dbg & 0x200)) gemm_lin<UPW>(acc, wrs, voff, so, (unsigned)NXT * 1024u, dxl + b * XP + 4 * q, NXT);
+      if (MULTI) {
+        f32x4 acc[UPW];
 #pragma unroll
-      for (int u = 0; u < UPW; ++u) st4(dhc + ((size_t)((L - 1) * UT + wave * UPW + u)) * 256 + lane * 4, acc[u]);
+        for (int u = 0; u < UPW; ++u) acc[u] = ld4(dhc + ((size_t)((L - 1) * UT + wave * UPW + u)) * 256 + lane * 4);
+        if (!(dbg & 0x200)) gemm_lin<UPW>(acc, wrs, voff, so, (unsigned)NXT * 1024u, dxl + b * XP + 4 * q, 0, NXT);
+#pragma unroll
+        for (int u = 0; u < UPW; ++u) st4(dhc + ((size_t)((L - 1) * UT + wave * UPW + u)) * 256 + lane * 4, acc[u]);
+      } else {
+        const int kend = (HELP && !virt) ? KX0 : NXT;   // the rest was multiplied after the products
+        if (!(dbg & 0x200)) gemm_lin<UPW>(car, wrs, voff, so, (unsigned)NXT * 1024u, dxl + b * XP + 4 * q, 0, kend);
+      }
     }
     PMG_TICK(6)
     __syncthreads();  // dxl / dtl / red reusable
@@ -754,7 +786,7 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
     for (int l = 0; l < L; ++l)
 #pragma unroll
       for (int u = 0; u < UPW; ++u) {
-        const f32x4 v = ld4(dhc + ((size_t)(l * UT + wave * UPW + u)) * 256 + lane * 4);
+        const f32x4 v = MULTI ? ld4(dhc + ((size_t)(l * UT + wave * UPW + u)) * 256 + lane * 4) : car[u];
         const int row = row0 + b;
         if (row < B) st4(a.grad_h0 + ((size_t)l * B + row) * H + 16 * (wave * UPW + u) + 4 * q, v);
       }
