@@ -478,7 +478,7 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
       PMG_TICK(7)
     }
    }
-  } else
+  } else {
   for (int p = N; p >= 0; --p) {
     const bool virt = (p == N);
     // dlogits_{p-1} inputs (probabilities, target token; nothing recurrent) are requested here, one
@@ -747,6 +747,12 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
       dxl[tid * XP + 1] = a1 * (dpo - s);
       dxl[tid * XP + 2] = a2 * (dno - s);
     }
+    if (HELP && !MULTI && !virt) {
+      // groups 1 .. KX0-1 hold dpush rows only (ready since the last barrier); group 0 also holds
+      // the three control gradients the helpers are forming right now
+      const unsigned so = a.oWXt + (unsigned)(wave * UPW) * (unsigned)NXT * 1024u;
+      if (!(dbg & 0x200)) gemm_lin<UPW>(car, wrs, voff, so, (unsigned)NXT * 1024u, dxl + b * XP + 4 * q, 1, KX0);
+    }
     __syncthreads();
     PMG_TICK(5)
     // ------------------------------------------------------------ DX slab + extras product
@@ -767,13 +773,14 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
 #pragma unroll
         for (int u = 0; u < UPW; ++u) st4(dhc + ((size_t)((L - 1) * UT + wave * UPW + u)) * 256 + lane * 4, acc[u]);
       } else {
-        const int kend = (HELP && !virt) ? KX0 : NXT;   // the rest was multiplied after the products
+        const int kend = (HELP && !virt) ? 1 : NXT;   // the rest was multiplied while the helpers finished the stack
         if (!(dbg & 0x200)) gemm_lin<UPW>(car, wrs, voff, so, (unsigned)NXT * 1024u, dxl + b * XP + 4 * q, 0, kend);
       }
     }
     PMG_TICK(6)
     __syncthreads();  // dxl / dtl / red reusable
     PMG_TICK(7)
+  }
   }
 #ifdef PMG_PROFILE
   if (prof && g == 0 && (tid & 63) == 0)

@@ -78,6 +78,22 @@ def test_parity_deep_wide_stack_crosses_the_lds_boundary(gpu):
     assert r['boundary'] <= 2
 
 
+@pytest.mark.parametrize('over,B,T', [
+    (dict(stack_width=64, stack_depth=2), 19, 7),            # every helper thread owns a column; rows 0/1 only
+    (dict(stack_width=3, stack_depth=2, vocab_size=97), 5, 6),   # shallowest stack the ABI admits; V > 64
+    (dict(stack_width=50, stack_depth=3), 33, 2),            # one decoder step
+    (dict(stack_width=17, stack_depth=9, vocab_size=189), 17, 26),  # bursts end inside / past the slab
+    (dict(stack_width=50, stack_depth=50, n_layers=2), 18, 24),  # carry through the global slab (2 layers)
+    (dict(stack_width=64, stack_depth=40, vocab_size=30), 16, 90),  # every live-row regime, widest stack
+], ids=['w64d2', 'd2v97', 't2', 'w17d9v189', 'l2', 'w64d40t90'])
+def test_hidden512_helper_wave_edges(gpu, over, B, T):
+    """Hidden 512 runs the BPTT with four helper waves (gate-gradient slab stores, stack backward of
+    rows >= 2, dlogits, DX slab off the recurrent chain; pmg_bwd.hip): the shapes that stress its
+    indexing -- column ownership, buffer-bounds masking of the live rows, the rows 0/1 finish."""
+    cfg = dict(P.TINY, rnn_cell_size=512, **over)
+    P.check_train(cfg, B=B, T=T, tol=TOL)
+
+
 def test_train_parity_cfg1(gpu):
     P.check_train(P.CFG1, B=64, T=100, tol=TOL)
 
