@@ -827,8 +827,8 @@ static hipError_t launch_bwd_t(const BwdArgs* a, hipStream_t st) {
 hipError_t pmg_launch_bwd(const BwdArgs* a, hipStream_t st) {
   const bool m = a->L > 1;
   switch (a->H) {
-    case 128: return m ? launch_bwd_t<1, true>(a, st) : launch_bwd_t<1, false>(a, st);
-    case 256: return m ? launch_bwd_t<2, true>(a, st) : launch_bwd_t<2, false>(a, st);
+    case 128: return m ? launch_bwd_t<1, true, PMG_BWD_HELP != 0>(a, st) : launch_bwd_t<1, false, PMG_BWD_HELP != 0>(a, st);
+    case 256: return m ? launch_bwd_t<2, true, PMG_BWD_HELP != 0>(a, st) : launch_bwd_t<2, false, PMG_BWD_HELP != 0>(a, st);
     case 512: return m ? launch_bwd_t<4, true, PMG_BWD_HELP != 0>(a, st) : launch_bwd_t<4, false, PMG_BWD_HELP != 0>(a, st);
     case 1024: return m ? launch_bwd_t<8, true>(a, st) : launch_bwd_t<8, false>(a, st);
   }
