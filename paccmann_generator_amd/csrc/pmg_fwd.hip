@@ -94,40 +94,61 @@ struct NoSide {
 // LDS or all global (wave-uniform `lds`), and the only rows a thread needs from outside its own
 // range -- old[d0-1] and old[d1] -- are read before barrier B1, i.e. before anybody writes
 // (s_end = old[d1]).  q[] is a ring of own rows requested ahead (slot of old[d0+1+k] is (k-1)&3).
+// a wave-uniform pointer the register allocator may have parked in vector registers: back to SGPRs
+// (two v_readfirstlane instead of a waterfall loop around every buffer access built from it)
+template <class T> __device__ __forceinline__ T* pmg_uniform_ptr(T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
 struct StackSide {
   static constexpr bool kActive = true;
-  __amdgpu_buffer_rsrc_t Sold, Snew;  // old / new global stack slab of this row group
-  unsigned vcol;                      // byte offset of this thread's column inside a stack row
-  float* sl;                          // LDS: this thread's column of stack row 0
+  // fp32 MFMA and fp32 VALU share the SIMD's ALUs, so every vector instruction of a side-job call is
+  // time taken from the product it rides on.  Row indices are therefore wave-uniform (all address
+  // arithmetic is scalar: one descriptor per row, built in SGPRs), rows that hold no data read as
+  // zero through the descriptor's bounds (global slab) or because the LDS rows start zeroed, and
+  // threads past the last stack column carry a lane offset outside every row (loads give zero,
+  // stores are dropped) instead of a predicate.
+  const float* Sold;   // old / new global stack slab of this row group (wave-uniform)
+  float* Snew;
+  unsigned vcol;       // byte offset of this thread's column inside a stack row; 0x40000000 for no column
+  float* sl;           // LDS: this thread's column of stack row 0
   f32x4 anoop, apush, apop, s_prev, s_cur, s_end, q[4];
   int d0, d1, rows, old_hi, sj, dch;  // dch: calls after which every thread of the workgroup is done
-  unsigned rstr;  // floats per stack row: W*16
-  bool on, lds, hist;  // lds: own rows in LDS (wave-uniform); hist: new rows are also kept in the global slab
+  unsigned rstr;       // floats per stack row: W*16
+  bool on, lds, hist;  // on: this thread has a column (per lane); lds: own rows in LDS (wave-uniform); hist: new rows are also kept in the global slab
+  __device__ __forceinline__ f32x4 ldg(const int d) const {   // row d of the old global slab; zero past old_hi
+    const __amdgpu_buffer_rsrc_t r = pmg_rsrc(pmg_uniform_ptr(Sold) + (size_t)d * rstr, (d <= old_hi) ? rstr * 4u : 0u);
+    return bl4s(r, vcol);
+  }
+  __device__ __forceinline__ void stg(const int d, const f32x4 v) const {
+    const __amdgpu_buffer_rsrc_t r = pmg_rsrc(pmg_uniform_ptr(Snew) + (size_t)d * rstr, rstr * 4u);
+    bs4s(r, vcol, v);
+  }
   __device__ __forceinline__ f32x4 ldrow(const int d) const {
     if (lds) return ld4(sl + (size_t)d * rstr);
-    return bl4s(Sold, (unsigned)d * rstr * 4u + vcol);
+    return ldg(d);
   }
   __device__ __forceinline__ void strow(const int d, const f32x4 v) const {
     if (lds) {
-      st4(sl + (size_t)d * rstr, v);
-      if (hist) bs4s(Snew, (unsigned)d * rstr * 4u + vcol, v);
+      if (on) st4(sl + (size_t)d * rstr, v);
+      if (hist) stg(d, v);
     } else {
-      bs4s(Snew, (unsigned)d * rstr * 4u + vcol, v);
+      stg(d, v);
     }
   }
   template <int U> __device__ __forceinline__ void step() {
     if (sj >= dch) return;  // uniform: nothing left for anybody
-    const int d = d0 + sj;
+    const int d = d0 + sj;  // uniform
     f32x4 nxt = q[U];
     if (sj + 4 < dch) {  // uniform: somebody will consume this slot again
       const int dn = d + 5;
       q[U] = ldrow(dn < d1 ? dn : d1 - 1);  // own rows only
     }
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    nxt = (d + 1 == d1) ? s_end : nxt;
-    nxt = (d + 1 <= old_hi) ? nxt : z4;
+    if (d + 1 == d1) nxt = s_end;           // uniform: the row above the part comes from the other part
     const f32x4 nw = anoop * s_cur + apush * s_prev + apop * nxt;
-    if (on && sj < rows) strow(d, nw);
+    if (sj < rows) strow(d, nw);            // uniform
     s_prev = s_cur;
     s_cur = nxt;
     ++sj;
@@ -394,6 +415,8 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
 
   // ---------------------------------------------------------------- init
   for (int idx = tid; idx < 16 * PMG_XTP; idx += NTHR) xtop[idx] = 0.0f;
+  // LDS stack rows start at zero: the side job reads rows that hold no data yet without a mask
+  for (int idx = tid; idx < a.KL * W * 16; idx += NTHR) slds[idx] = 0.0f;
   if (tid < 32) misc[tid] = 0;
   if (decode) {
     // h0 = latent_to_hidden(latent): same value for every layer (reinforce.py:160-170 path)
@@ -484,8 +507,7 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
     // ------------------------------------------------------------ stack: first rows requested early
     const int st_slot_old = teacher ? i : (i & 1);
     const int st_slot_new = teacher ? i + 1 : ((i + 1) & 1);
-    const __amdgpu_buffer_rsrc_t st_Sold = pmg_rsrc(a.SB + ((size_t)st_slot_old * G + g) * a.SW, (unsigned)a.SW * 4u);
-    const unsigned st_vcol = (unsigned)st_cofs * 4u;
+    const unsigned st_vcol = st_col ? (unsigned)st_cofs * 4u : 0x40000000u;  // no column: outside every row
     // Live rows.  Entering step i only rows 0..i-1 of a stack that started at zero can be non-zero,
     // and row d of the new stack can reach the stack top (the only way the stack is ever read) no
     // earlier than step i+d: rows beyond min(i, N-1-i) are neither computed nor stored, and rows
@@ -507,7 +529,8 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
     const int st_dch = (st_bnd > st_nrows - st_bnd) ? st_bnd : st_nrows - st_bnd;
     const int st_rows = st_d1 - st_d0;
     const bool st_own_lds = KL > 0 && (st_part == 0 || st_nrows <= KL);  // scalar
-    const bool st_on = st_col && st_d0 < st_d1 && !(dbg & 0x100) && i < N;
+    const bool st_act = st_d0 < st_d1 && !(dbg & 0x100) && i < N;  // scalar: this depth part has rows
+    const bool st_on = st_col && st_act;
     // target token of step i-1 (teacher): requested here, used after the extras GEMM
     int cs_y = 0;
     if (teacher && i >= 1 && row0 + cs_bb < B) cs_y = min(max((int)a.tok_in[(size_t)i * B + row0 + cs_bb], 0), V - 1);
@@ -516,20 +539,20 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
     // d0+2 .. d0+5: requested here, before barrier B1, i.e. before anybody overwrites an LDS row; only
     // rows that hold data are requested (memory operations are not free here), the rest stay zero
     StackSide stk;
-    stk.Sold = st_Sold; stk.vcol = st_vcol; stk.rstr = (unsigned)W * 16u; stk.sl = slds + st_cofs;
-    stk.d0 = st_on ? st_d0 : 0; stk.d1 = st_on ? st_d1 : 1; stk.dch = st_dch; stk.rows = st_rows;
+    stk.Sold = a.SB + ((size_t)st_slot_old * G + g) * a.SW; stk.vcol = st_vcol; stk.rstr = (unsigned)W * 16u;
+    stk.sl = slds + st_cofs;
+    stk.d0 = st_act ? st_d0 : 0; stk.d1 = st_act ? st_d1 : 1; stk.dch = st_dch; stk.rows = st_rows;
     stk.old_hi = st_old_hi; stk.on = st_on; stk.lds = st_own_lds; stk.hist = keep;
     f32x4 st_pm = zero4, st_c0 = zero4, st_n0 = zero4;
     stk.s_end = zero4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) stk.q[j] = zero4;
-    if (st_on) {
-      const unsigned rb = stk.rstr * 4u;
+    if (st_act) {   // scalar; a thread without a column reads zeros (global) or column 0 (LDS) and stores nothing
       // rows outside the own range live where THEIR depth says: LDS below KL, the global slab above
       if (st_d0 > 0 && st_d0 - 1 <= st_old_hi)
-        st_pm = (st_d0 - 1 < KL) ? ld4(stk.sl + (size_t)(st_d0 - 1) * stk.rstr) : bl4s(st_Sold, (unsigned)(st_d0 - 1) * rb + st_vcol);
+        st_pm = (st_d0 - 1 < KL) ? ld4(stk.sl + (size_t)(st_d0 - 1) * stk.rstr) : stk.ldg(st_d0 - 1);
       if (st_d1 <= st_old_hi && st_d1 < D)
-        stk.s_end = (st_d1 < KL) ? ld4(stk.sl + (size_t)st_d1 * stk.rstr) : bl4s(st_Sold, (unsigned)st_d1 * rb + st_vcol);
+        stk.s_end = (st_d1 < KL) ? ld4(stk.sl + (size_t)st_d1 * stk.rstr) : stk.ldg(st_d1);
       if (st_d0 <= st_old_hi) st_c0 = stk.ldrow(st_d0);
       if (st_d0 + 1 <= st_old_hi && st_d0 + 1 < st_d1) st_n0 = stk.ldrow(st_d0 + 1);
 #pragma unroll
@@ -647,7 +670,6 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
     // Each thread walks its depth range one row per side-job call; rows d0-1 .. d0+3 were
     // requested before the extras GEMM, every call requests row d+4.
     f32x4 apush = zero4, apop = zero4, anoop = zero4, pv = zero4;
-    const __amdgpu_buffer_rsrc_t st_Snew = pmg_rsrc(a.SB + ((size_t)st_slot_new * G + g) * a.SW, (unsigned)a.SW * 4u);
     if (st_on) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -671,7 +693,7 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
     }
     // first row of every thread now (row 0 is the stack top the W_ih product needs right after
     // the W_hh product); the remaining rows stream under the W_hh GEMM, one per double K group
-    stk.Snew = st_Snew; stk.anoop = anoop; stk.apush = apush; stk.apop = apop; stk.sj = 1;
+    stk.Snew = a.SB + ((size_t)st_slot_new * G + g) * a.SW; stk.anoop = anoop; stk.apush = apush; stk.apop = apop; stk.sj = 1;
     {
       const f32x4 pm = (st_d0 == 0) ? pv : ((st_d0 - 1 <= st_old_hi) ? st_pm : zero4);
       const f32x4 c0 = (st_d0 <= st_old_hi) ? st_c0 : zero4;
