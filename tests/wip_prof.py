@@ -39,5 +39,6 @@ fwd(); bwd(_ffi.PMG_FLAG_SKIP_WGRAD); torch.cuda.synchronize()
 os.environ['PMG_DEBUG'] = hex(0x8000 | int(os.environ.get('ABL', '0'), 16))
 for which in os.environ.get('WHICH', 'fwd,bwd').split(','):
     if which == 'fwd': fwd()
+    elif which == 'dec': ops.decode(w, latent, 2, 3, T, temperature=0.8, seed=1, early_exit=False)
     else: bwd(_ffi.PMG_FLAG_SKIP_WGRAD)
     torch.cuda.synchronize()
