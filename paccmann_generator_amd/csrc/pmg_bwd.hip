@@ -46,9 +46,6 @@
 #ifndef PMG_HELP_PRIO
 #define PMG_HELP_PRIO 3
 #endif
-#ifndef PMG_HELP_X
-#define PMG_HELP_X 0
-#endif
 #ifndef PMG_HBLK
 #define PMG_HBLK 4      // stack rows per load burst of a helper thread
 #endif
@@ -352,17 +349,10 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
         const int g_lim = (p < N - 1 - p) ? p : N - 1 - p;
         const int s_hi = s_lim < D - 1 ? s_lim : D - 1;
         const int g_hi = g_lim < D - 1 ? g_lim : D - 1;
-#if PMG_HELP_X == 1
-        const float* Sprev = a.SB + ((size_t)0 * G + g) * a.SW;   // experiment: cache-resident rows (wrong results)
-#else
         const float* Sprev = a.SB + ((size_t)p * G + g) * a.SW;
-#endif
         const float* dSin = a.DS + ((size_t)((p + 1) & 1) * G + g) * a.SW;
         const __amdgpu_buffer_rsrc_t srs = rsrc_uniform(Sprev, (p == 0 || s_hi < 0) ? 0u : (unsigned)(s_hi + 1) * rs4);
         const __amdgpu_buffer_rsrc_t grs = rsrc_uniform(dSin, (p == N - 1 || g_hi < 0) ? 0u : (unsigned)(g_hi + 1) * rs4);
-#if PMG_HELP_X == 2
-        nrows = nrows < 1 ? nrows : 1;                            // experiment: no part 1 (wrong results)
-#endif
         // (only the per-lane offset of a buffer access is checked against the bounds, so the row
         // offsets go there: one add per row)
         constexpr int SAUX = (PMG_NT & 4) ? 2 : 0;
