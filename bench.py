@@ -291,8 +291,7 @@ def main():
     def step():
         tokens, lens = learner.sample_tokens(latent, seq_index_base=rank * B, early_exit=False)
         padded = pad_rows_on_device(tokens, lens, STOP, t_max=T + 2)
-        learner._tokens_trusted = True      # rows come straight from pmg_decode
-        learner.learn(latent, padded, valid_idx, rewards, lrps=1)
+        learner.learn(latent, padded, valid_idx, rewards, lrps=1, trusted_tokens=True)   # rows come straight from pmg_decode
 
     tokens_per_step = B * T
     if args.config == 'cfg5':

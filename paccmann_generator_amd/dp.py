@@ -37,6 +37,17 @@ def all_reduce_(t: torch.Tensor, op=None, group=None) -> torch.Tensor:
     return t
 
 
+def broadcast_(t: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
+    """In-place broadcast that works for device tensors under both RCCL and gloo."""
+    if _stage_on_host(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous [lo, hi) slice of ``n`` sequences owned by ``rank`` (sizes differ by <= 1)."""
     base, rem = divmod(int(n), int(world))
@@ -53,16 +64,35 @@ def global_sum(value: float, device, group=None) -> float:
     return float(t.item())
 
 
+def global_max(value: int, device, group=None) -> int:
+    """Largest of a host integer over the ranks (the global ``T_max`` of a sharded batch: the
+    reference pads every molecule to the longest VALID one of the whole batch and does not mask the
+    padded positions, reinforce_omics.py:304,322-332, so every rank has to run that many steps)."""
+    if group is None and not (dist.is_available() and dist.is_initialized()):
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    all_reduce_(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
 def all_reduce_gradients_(params: Iterable[torch.nn.Parameter], group=None) -> int:
     """Sum ``p.grad`` over the ranks with one collective on one flat fp32 buffer.
 
     The buffer covers the FIXED list ``params`` on every rank: a parameter without a gradient on
-    this rank takes part as zeros (and receives the sum), so ranks whose backward reached different
-    sets of parameters -- or did not run at all -- still exchange buffers of one size.  Returns the
-    number of floats reduced."""
+    this rank takes part as zeros, so ranks whose backward reached different sets of parameters --
+    or did not run at all -- still exchange buffers of one size.  A parameter that has a gradient
+    on NO rank keeps ``grad = None`` (the has-gradient flags travel in the same buffer), so that an
+    optimizer with weight decay leaves it alone exactly as the single-process run does.  Returns
+    the number of floats reduced."""
     ps = list(params)
-    flat, _ = _reduce_flat(ps, [], group)
-    _scatter_grads(ps, flat, [True] * len(ps))
+    local = [p.grad is not None for p in ps]
+    flat, n_tail = _reduce_flat(ps, [], group)
+    if all(local):
+        take = local                       # no host synchronisation needed
+    else:
+        flags = flat[flat.numel() - n_tail:].cpu().tolist()
+        take = [f > 0.0 for f in flags[:len(ps)]]
+    _scatter_grads(ps, flat, take)
     return sum(p.numel() for p in ps)
 
 
@@ -104,7 +134,8 @@ def data_parallel_step(dec_params: Sequence[torch.nn.Parameter], enc_params: Seq
 
     ``backward_fn()`` runs forward + backward with scale 1 on the ``num_mols`` valid molecules of this
     rank, leaves gradient SUMS in ``.grad`` and returns the loss sum; it is not called when
-    ``num_mols == 0``.  The loss sum and ``reward_sum`` may be numbers or 0-dim tensors.  Then ONE all-reduce carries [gradients | has-gradient flags |
+    ``num_mols == 0``.  The loss sum and ``reward_sum`` may be numbers or 0-dim tensors
+    (``reward_sum`` also a callable evaluated after ``backward_fn``).  Then ONE all-reduce carries [gradients | has-gradient flags |
     loss sum | reward sum | count]; every rank takes part, also one with nothing to contribute.
     Everything is divided by the global count, clip and the optimizer step run replicated.  When no
     rank has a valid molecule the update is skipped everywhere.
@@ -128,6 +159,8 @@ def data_parallel_step(dec_params: Sequence[torch.nn.Parameter], enc_params: Seq
     for p in enc_params:
         p.grad = None
     loss_sum = backward_fn() if num_mols > 0 else 0.0
+    if callable(reward_sum):            # known only after the backward pass (pipelined host scoring)
+        reward_sum = reward_sum()
     flat, n_tail = _reduce_flat(params, (loss_sum, reward_sum, float(num_mols)), group)
     tail = flat[flat.numel() - n_tail:]
     n_glob = tail[-1].clone()

@@ -9,9 +9,10 @@ SURVEY.md section 2 rows 6-10); this module only spreads a per-item function ove
 keeps the order, so that it can be handed to ``Reinforce(..., is_valid_batch=HostPool(is_valid))`` or
 used inside a ``reward_fn``.
 
-Workers are forked BEFORE the parent touches the GPU when the pool is created early (recommended:
-build the pool before the models); with the ``spawn`` start method it is safe at any time, at the
-price of importing the function's module in every worker.
+Start method: ``fork`` is cheapest but only safe while the parent has not initialised the GPU (a
+forked HIP runtime has dead helper threads and possibly held locks), so the default is ``fork`` before
+``torch.cuda.is_initialized()`` and ``forkserver`` after; ``spawn`` / ``forkserver`` import the
+function's module in every worker (it must be picklable by reference).
 """
 from __future__ import annotations
 
@@ -37,17 +38,26 @@ def _run(chunk):
     return out
 
 
+def _gpu_in_use() -> bool:
+    try:
+        import torch
+        return bool(torch.cuda.is_initialized())
+    except Exception:      # pragma: no cover
+        return False
+
+
 class HostPool:
     """``pool(items) -> [fn(item) for item in items]`` evaluated by ``workers`` processes, order kept.
 
     fn:       picklable per-item function (e.g. SMILES -> bool, SMILES -> float)
     workers:  processes (default: the CPUs this process may run on, at most 16)
     chunk:    items per task; a failing item yields ``on_error`` instead of raising
-    start:    multiprocessing start method ('fork' is cheapest; use 'spawn' once the GPU is in use)
+    start:    multiprocessing start method; None = 'fork' while this process has not initialised the
+              GPU, 'forkserver' once it has
     """
 
     def __init__(self, fn: Callable, workers: Optional[int] = None, chunk: int = 128, on_error=None,
-                 start: str = 'fork'):
+                 start: Optional[str] = None):
         if workers is None:
             try:
                 workers = len(os.sched_getaffinity(0))
@@ -55,6 +65,9 @@ class HostPool:
                 workers = os.cpu_count() or 1
             workers = max(1, min(16, workers))
         self.fn, self.workers, self.chunk, self.on_error = fn, int(workers), int(chunk), on_error
+        if start is None:
+            start = 'forkserver' if _gpu_in_use() else 'fork'
+        self.start = start
         self._pool = mp.get_context(start).Pool(self.workers, initializer=_init, initargs=(fn,)) \
             if self.workers > 1 else None
 
@@ -82,8 +95,13 @@ class HostPool:
     def __exit__(self, *exc):
         self.close()
 
-    def __del__(self):      # best effort
+    def terminate(self) -> None:
+        if self._pool is not None:
+            self._pool.terminate()
+            self._pool = None
+
+    def __del__(self):      # best effort, and never a join() that could block interpreter shutdown
         try:
-            self.close()
+            self.terminate()
         except Exception:
             pass

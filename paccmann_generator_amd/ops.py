@@ -480,8 +480,11 @@ class TokenTable:
         self.device = torch.device(device)
         self._out: Dict[tuple, tuple] = {}
 
-    def buffers(self, B: int, max_len: int):
+    def buffers(self, B: int, max_len: int, fresh: bool = False):
         cap = B * max_len * self.max_tok_bytes
+        if fresh:       # several batches in flight at once (micro-batches of a pipelined step)
+            return (torch.empty(B + 1, dtype=torch.int64, device=self.device),
+                    torch.empty(cap, dtype=torch.uint8, device=self.device))
         key = (B, max_len)
         buf = self._out.get(key)
         if buf is None:
@@ -493,10 +496,10 @@ class TokenTable:
 
 
 @torch.no_grad()
-def detokenize_device(table: TokenTable, tokens: Tensor, lens: Tensor):
+def detokenize_device(table: TokenTable, tokens: Tensor, lens: Tensor, fresh: bool = False):
     """Stream-ordered, no synchronisation: (out_off [B+1] int64, out_bytes uint8) on the device;
     row b is out_bytes[out_off[b]:out_off[b+1]].  The buffers belong to ``table`` and are reused by
-    the next call with the same (B, max_len)."""
+    the next call with the same (B, max_len), unless ``fresh`` asks for buffers of the call's own."""
     if tokens.dtype != torch.int64 or lens.dtype != torch.int32:
         raise _ffi.PmgError('pmg_detokenize: tokens must be int64 and lens int32')
     tokens = tokens.contiguous()
@@ -504,7 +507,7 @@ def detokenize_device(table: TokenTable, tokens: Tensor, lens: Tensor):
     B, N = tokens.shape
     if lens.numel() != B:
         raise _ffi.PmgError('pmg_detokenize: one length per row required')
-    out_off, out_bytes = table.buffers(B, N)
+    out_off, out_bytes = table.buffers(B, N, fresh)
     _detokenize_op(tokens, lens, table.tab_off, table.tab_bytes, table.max_tok_bytes, out_off, out_bytes)
     return out_off, out_bytes
 
@@ -514,7 +517,12 @@ def detokenize(table: TokenTable, tokens: Tensor, lens: Tensor) -> List[str]:
     (reinforce.py:172-176): one device pass, two device->host copies, B string slices."""
     if tokens.shape[0] == 0:
         return []
-    out_off, out_bytes = detokenize_device(table, tokens, lens)
+    return detokenize_collect(table, *detokenize_device(table, tokens, lens))
+
+
+def detokenize_collect(table: TokenTable, out_off: Tensor, out_bytes: Tensor) -> List[str]:
+    """Host half of ``detokenize``: two device->host copies on the CURRENT stream (a pipelined caller
+    runs it on a side stream that waits for this batch only) and B string slices."""
     off = out_off.cpu().tolist()
     blob = out_bytes[:off[-1]].cpu().numpy().tobytes()
     if table.ascii:

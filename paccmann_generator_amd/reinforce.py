@@ -40,7 +40,7 @@ class Reinforce(object):
 
     def __init__(self, generator, encoder, params, model_name, logger, is_valid: Optional[Callable] = None,
                  reward_fn: Optional[Callable] = None, process_group=None, score_fn: Optional[Callable] = None,
-                 is_valid_batch: Optional[Callable] = None):
+                 is_valid_batch: Optional[Callable] = None, micro_batches: Optional[int] = None):
         """Same positional arguments as reinforce.py:16.  Keyword-only extras:
 
         is_valid:      host validity check replacing Chem.MolFromSmiles (reinforce.py:195)
@@ -49,6 +49,8 @@ class Reinforce(object):
         reward_fn:     host reward ``f(smiles, target) -> array`` (reinforce_omics.py:209-222)
         score_fn:      host scoring used by generate_compounds_and_evaluate (defaults to reward_fn)
         process_group: torch.distributed group for data-parallel latent sharding
+        micro_batches: k > 1 pipelines the host scoring of a step against its GPU work (see
+                       _policy_gradient_pipelined); also read from params['micro_batches']; default 1
         """
         super(Reinforce, self).__init__()
         self.generator = generator
@@ -76,6 +78,8 @@ class Reinforce(object):
         self.reward_fn = reward_fn
         self.score_fn = score_fn
         self.process_group = process_group
+        self.micro_batches = max(1, int(micro_batches if micro_batches is not None else params.get('micro_batches', 1)))
+        self._side_stream = None
 
         # reinforce.py:59-77
         if params.get('save_untrained', True):
@@ -129,7 +133,8 @@ class Reinforce(object):
         self._seq_base = lo
         return hi - lo
 
-    def sample_tokens(self, latent, seq_index_base: Optional[int] = None, early_exit: bool = True):
+    def sample_tokens(self, latent, seq_index_base: Optional[int] = None, early_exit: bool = True,
+                      advance: bool = True):
         """Device-side half of get_smiles_from_latent: (tokens [B,generate_len], lengths [B])."""
         if seq_index_base is None:
             seq_index_base = getattr(self, '_seq_base', 0)
@@ -140,7 +145,7 @@ class Reinforce(object):
             end_token=torch.Tensor([lang.stop_index]).long(),
             generate_len=self.generate_len,
             search=SamplingSearch(temperature=self.temperature),
-            seq_index_base=seq_index_base, early_exit=early_exit)
+            seq_index_base=seq_index_base, early_exit=early_exit, advance=advance)
 
     def _token_table(self, lang):
         """Device table for pmg_detokenize when the language exposes ``index_to_token`` (pytoda's
@@ -184,12 +189,7 @@ class Reinforce(object):
             strings = [lang.token_indexes_to_smiles(r.tolist()) for r in rows]
             numericals = [torch.cat([r.long(), stops]) for r in rows]
         smiles = [lang.selfies_to_smiles(s) for s in strings]
-        if self.is_valid_batch is not None:
-            ok = [bool(v) for v in self.is_valid_batch(smiles)]
-        elif self.is_valid is not None:
-            ok = [bool(self.is_valid(s)) for s in smiles]
-        else:
-            raise RuntimeError('no validity check available: pass is_valid= (RDKit is not importable)')
+        ok = self._validity(smiles)
         valid_idxs = [i for i in range(len(ok)) if ok[i]]
         keep = [i for i in range(len(ok)) if not (remove_invalid and not ok[i])]
         if self.logger is not None:
@@ -197,13 +197,22 @@ class Reinforce(object):
         nums = numericals.subset(keep) if isinstance(numericals, StopRows) else [numericals[i] for i in keep]
         return [smiles[i] for i in keep], nums, valid_idxs
 
+    def _validity(self, smiles):
+        """reinforce.py:195-196 over a list: one bool per molecule."""
+        if self.is_valid_batch is not None:
+            return [bool(v) for v in self.is_valid_batch(smiles)]
+        if self.is_valid is not None:
+            return [bool(self.is_valid(s)) for s in smiles]
+        raise RuntimeError('no validity check available: pass is_valid= (RDKit is not importable)')
+
     # ------------------------------------------------------------------ learning
-    def learn(self, latent_z, padded_nums, valid_idx, rewards, lrps: int = 1):
+    def learn(self, latent_z, padded_nums, valid_idx, rewards, lrps: int = 1, trusted_tokens: bool = False):
         """reinforce_omics.py:301-342 given sampled + scored molecules.
 
         latent_z [1,B,latent_size] (autograd-connected to the encoder), padded_nums
         [T_max,B_valid] (pad_sequence layout), valid_idx indices into B, rewards [B_valid].
-        Returns (mean_reward, loss) as 0-dim tensors.
+        Returns (mean_reward, loss) as 0-dim tensors.  ``trusted_tokens``: the rows were cut from
+        pmg_decode's own output (ids in range by construction), skip the host-side id range check.
 
         With a process group these are this rank's shard and the step is data parallel: the kernel
         forms gradient SUMS (scale 1), ONE all-reduce carries [gradients | loss sum | reward sum |
@@ -228,7 +237,7 @@ class Reinforce(object):
             hidden = dec.latent_to_hidden(
                 latent_z.to(dev).repeat(dec.n_layers, 1, lrps)[:, idx.to(dev), :])
             loss, _ = ops.reinforce_loss(dec.weights(), padded_nums.to(dev), hidden, rewards_t.to(dev), scale,
-                                         trusted_tokens=self._tokens_trusted)
+                                         trusted_tokens=trusted_tokens)
             loss.backward()
             return loss.detach()
 
@@ -245,10 +254,18 @@ class Reinforce(object):
         self.optimizer.step()
         return summed_reward, loss
 
-    _tokens_trusted = False   # set while the rows come from this object's own decode (ids in range by construction)
+    def _lrps(self):
+        """reinforce_omics.py:310-312: latent repeats per sample."""
+        if self.encoder is not None and \
+                self.generator.decoder.latent_dim == 2 * getattr(self.encoder, 'latent_size', -1):
+            return 2
+        return 1
 
     def _policy_gradient(self, latent_z, target):
         B_local = latent_z.shape[1]
+        if self.micro_batches > 1 and B_local > 0:
+            return self._policy_gradient_pipelined(latent_z, target)
+        ddp = self.process_group is not None
         try:
             if B_local > 0:
                 valid_smiles, valid_nums, valid_idx = self.get_smiles_from_latent(latent_z, remove_invalid=True)
@@ -261,30 +278,222 @@ class Reinforce(object):
             if self.logger is not None:
                 self.logger.warning('no valid molecule in the batch' +
                                     (' of this rank' if self.process_group is not None else ': update skipped'))
-            if self.process_group is None:
+            if not ddp:
                 return torch.tensor(0.0), 0.0
-            rewards, padded_nums = np.zeros(0, dtype=np.float32), torch.zeros(0, 0, dtype=torch.long)
+        # T_max of the step: the longest valid molecule (+ 2 stops) of the WHOLE batch -- over all ranks
+        # when the batch is sharded, because the padded positions are not masked (reinforce_omics.py:304,
+        # 322-332) and so every row's loss depends on it
+        t_max = self._local_t_max(valid_nums, valid_idx)
+        if ddp:
+            t_max = dp.global_max(t_max, self.device, self.process_group)
+        if len(valid_nums) == 0:
+            rewards, padded_nums, trusted = np.zeros(0, dtype=np.float32), torch.zeros(0, 0, dtype=torch.long), True
         else:
             rewards = self.get_reward(valid_smiles, target)
-            padded_nums = self._padded_valid(valid_nums, valid_idx)
-        lrps = 1
-        if self.encoder is not None and \
-                self.generator.decoder.latent_dim == 2 * getattr(self.encoder, 'latent_size', -1):
-            lrps = 2
-        r, loss = self.learn(latent_z, padded_nums, valid_idx, rewards, lrps)
+            padded_nums, trusted = self._padded_valid(valid_nums, valid_idx, t_max)
+        r, loss = self.learn(latent_z, padded_nums, valid_idx, rewards, self._lrps(), trusted_tokens=trusted)
         return r, float(loss)
 
-    def _padded_valid(self, valid_nums, valid_idx):
-        """pad_sequence(valid_nums) (reinforce_omics.py:304).  When the rows are the ones the device
-        detokeniser path just produced, the same [T_max, B_valid] matrix is built on the device from
-        the decoded tokens instead of from B_valid host tensors."""
+    # ------------------------------------------------------------------ pipelined step
+    def _sample_device(self, latent, seq_index_base: int, advance: bool = True, fresh: bool = False):
+        """Device half of get_smiles_from_latent, stream-ordered, no synchronisation: decode and -- for a
+        language with ``index_to_token`` -- the detokeniser launches.  Returns (tokens, lens, det) with
+        det = (out_off, out_bytes) on the device, or None."""
+        tokens, lens = self.sample_tokens(latent, seq_index_base=seq_index_base, advance=advance)
+        table = self._token_table(self.generator.smiles_language)
+        det = None
+        if table is not None and tokens.shape[0] > 0:
+            det = ops.detokenize_device(table, tokens, lens, fresh=fresh)
+        return tokens, lens, det
+
+    def _host_strings(self, tokens, lens, det):
+        """Host half: the molecule strings of a decoded batch (blocking device->host copies on the
+        CURRENT stream), reinforce.py:172-176."""
+        lang = self.generator.smiles_language
+        if tokens.shape[0] == 0:
+            return []
+        if det is not None:
+            return ops.detokenize_collect(self._token_table(lang), *det)
+        tok, ln = tokens.cpu(), lens.cpu().tolist()
+        return [lang.token_indexes_to_smiles(tok[r, :ln[r]].tolist()) for r in range(tok.shape[0])]
+
+    def _policy_gradient_pipelined(self, latent_z, target):
+        """One REINFORCE step (reinforce_omics.py:289-342) whose host scoring runs UNDER its GPU work.
+
+        The reference is serial: decode all -> detokenise / SELFIES / RDKit validity all
+        (reinforce.py:172-211) -> reward all (reinforce_omics.py:300) -> teacher-forced loop + backward.
+        With a process pool behind ``is_valid_batch`` / ``reward_fn`` the host stages cost about as much
+        as the GPU ones at B = 4096, so the batch is cut into ``micro_batches`` contiguous slices:
+
+          GPU  : D0 D1 .. Dk-1 |            L0   L1  ..  Lk-1        D = decode (+ detokeniser launches)
+          host :    V0 V1  ..  Vk-1 | R0   R1   ..   Rk-1             V = strings + validity, R = reward
+                                                                     L = teacher-forced pass + BPTT + weight gradients
+        Why two phases and not one: ``pad_sequence`` pads to the longest VALID molecule of the whole
+        batch and the padded positions are not masked (reinforce_omics.py:304,322-332), so every row's
+        loss depends on T_max, which is known only when every slice's validity is.  Validity therefore
+        overlaps the decodes, the rewards overlap the backward passes, and the GPU idles only for the
+        last slice's validity and the first slice's reward (1/k of each).
+
+        Same results as the serial step: Philox counters are keyed by the global row and all slices share
+        the step's offset, so the tokens are identical; the gradients of the slices accumulate (the loss
+        is a sum over molecules; scale = 1 / valid molecules of the whole batch, known before the first
+        backward pass); T_max is the batch's; clip + Adam run once.  The encoder is differentiated once,
+        through the summed latent gradient of the slices."""
+        import threading
+        gen, dec, dev = self.generator, self.generator.decoder, self.device
+        lang = gen.smiles_language
+        B_local = latent_z.shape[1]
+        k = min(self.micro_batches, B_local)
+        base = getattr(self, '_seq_base', 0)
+        self._seq_base = 0
+        ddp = self.process_group is not None
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=dev)
+        side = self._side_stream
+
+        # ---- phase 1, GPU: every slice's decode is queued now; an event marks the end of each
+        slices = []
+        with torch.no_grad():
+            lat = latent_z.detach()
+            for i in range(k):
+                lo, hi = dp.shard_range(B_local, i, k)
+                tokens, lens, det = self._sample_device(lat[:, lo:hi], base + lo, advance=False, fresh=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                slices.append(_Slice(lo, hi, tokens, lens, det, ev))
+        gen.skip_draws(self.generate_len)       # one batch, one advance of the Philox offset
+        err = []
+
+        def host_worker():
+            # validity of a slice as soon as its decode has finished (T_max needs all of them); rewards
+            # fill the time the host would otherwise wait for a decode, and follow in slice order
+            try:
+                nv = nr = 0
+                with torch.cuda.stream(side):
+                    while nr < k:
+                        if nv < k and (nr >= nv or slices[nv].event.query()):
+                            s = slices[nv]
+                            side.wait_event(s.event)        # copies of this slice wait for its decode only
+                            strings = self._host_strings(s.tokens, s.lens, s.det)
+                            smiles = [lang.selfies_to_smiles(x) for x in strings]
+                            ok = self._validity(smiles)
+                            s.n_ok = sum(ok)
+                            s.valid = [j for j in range(len(ok)) if ok[j]]
+                            s.smiles = [smiles[j] for j in s.valid]
+                            ln = s.lens.cpu().tolist()
+                            s.max_len = max((ln[j] for j in s.valid), default=-2)
+                            s.v_done.set()
+                            nv += 1
+                        else:
+                            s = slices[nr]
+                            s.rewards = np.asarray(self.get_reward(s.smiles, target), dtype=np.float32).reshape(-1) \
+                                if s.valid else np.zeros(0, dtype=np.float32)
+                            if s.rewards.shape[0] != len(s.valid):
+                                raise RuntimeError('reward_fn must return one reward per molecule')
+                            s.r_done.set()
+                            nr += 1
+            except BaseException as e:      # handed to the main thread, which re-raises
+                err.append(e)
+            finally:
+                for s in slices:
+                    s.v_done.set()
+                    s.r_done.set()
+
+        th = threading.Thread(target=host_worker, name='pmg-host-scoring', daemon=True)
+        th.start()
+
+        def wait(flag):
+            flag.wait()
+            if err:
+                th.join()
+                raise err[0]
+
+        for s in slices:
+            wait(s.v_done)
+        n_valid = sum(len(s.valid) for s in slices)
+        if self.logger is not None:
+            self.logger.info(f'{self.model_name}: SMILES validity: {100.0 * n_valid / max(1, B_local):.2f}%.')
+        t_max = max(s.max_len for s in slices) + 2
+        if ddp:
+            t_max = dp.global_max(t_max, dev, self.process_group)
+        if n_valid == 0:
+            if self.logger is not None:
+                self.logger.warning('no valid molecule in the batch' + (' of this rank' if ddp else ': update skipped'))
+            if not ddp:
+                th.join()
+                return torch.tensor(0.0), 0.0
+
+        # ---- phase 2: slice i is back-propagated as soon as its rewards are in
+        lrps = self._lrps()
+        enc_params = list(self.encoder.parameters()) if self.encoder is not None else []
+        dec_params = list(dec.parameters())
+        leaf = latent_z.detach().to(dev)
+        if latent_z.requires_grad:
+            leaf.requires_grad_(True)
+
+        def run(scale):
+            total = torch.zeros((), dtype=torch.float32, device=dev)
+            for s in slices:
+                wait(s.r_done)
+                if not s.valid:
+                    continue
+                idx = torch.as_tensor(s.valid, dtype=torch.long, device=dev)
+                padded = pad_rows_on_device(s.tokens.index_select(0, idx), s.lens.index_select(0, idx),
+                                            lang.stop_index, t_max=t_max)
+                dec._update_batch_size(len(s.valid))
+                hidden = dec.latent_to_hidden(leaf.repeat(dec.n_layers, 1, lrps)[:, idx + s.lo, :])
+                r_t = torch.from_numpy(s.rewards).to(dev)
+                loss, _ = ops.reinforce_loss(dec.weights(), padded, hidden, r_t, scale, trusted_tokens=True)
+                loss.backward()
+                total = total + loss.detach()
+            if leaf.grad is not None:       # the encoder is differentiated once (reinforce_omics.py:87,313)
+                latent_z.backward(leaf.grad.to(latent_z.device))
+            return total
+
+        def reward_sum():
+            return float(sum(float(s.rewards.sum(dtype=np.float64)) for s in slices))
+
+        try:
+            if ddp:
+                r, loss, _ = dp.data_parallel_step(dec_params, enc_params, self.optimizer, lambda: run(1.0), n_valid,
+                                                   reward_sum, self.grad_clipping, group=self.process_group)
+            else:
+                self.optimizer.zero_grad()
+                loss = run(1.0 / n_valid)
+                r = torch.mean(torch.from_numpy(np.concatenate([s.rewards for s in slices])).float())
+                if self.grad_clipping is not None:
+                    torch.nn.utils.clip_grad_norm_(dec_params + enc_params, self.grad_clipping)
+                self.optimizer.step()
+        finally:
+            th.join()
+        if err:
+            raise err[0]
+        return r, float(loss)
+
+    @staticmethod
+    def _local_t_max(valid_nums, valid_idx) -> int:
+        """Rows of pad_sequence(valid_nums): longest valid molecule + its two stop tokens; 0 without any."""
+        if len(valid_nums) == 0:
+            return 0
+        if isinstance(valid_nums, StopRows):
+            idx = torch.as_tensor(valid_nums.index, dtype=torch.long, device=valid_nums.lens.device)
+            return int(valid_nums.lens.index_select(0, idx).max().item()) + 2
+        return max(int(n.shape[0]) for n in valid_nums)
+
+    def _padded_valid(self, valid_nums, valid_idx, t_max: Optional[int] = None):
+        """pad_sequence(valid_nums) (reinforce_omics.py:304), zero-padded on to ``t_max`` rows when
+        given.  When the rows are the ones the device detokeniser path just produced, the same
+        [T_max, B_valid] matrix is built on the device from the decoded tokens instead of from B_valid
+        host tensors.  Returns (padded, trusted): trusted rows were cut from pmg_decode's own output,
+        their ids are in range by construction."""
         if isinstance(valid_nums, StopRows) and len(valid_idx) > 0 and valid_nums.index == list(valid_idx):
             idx = torch.as_tensor(valid_idx, dtype=torch.long, device=valid_nums.tokens.device)
-            self._tokens_trusted = True      # rows cut from pmg_decode's own output: ids are in range
             return pad_rows_on_device(valid_nums.tokens.index_select(0, idx), valid_nums.lens.index_select(0, idx),
-                                      valid_nums.stop_index)
-        self._tokens_trusted = False
-        return torch.nn.utils.rnn.pad_sequence(valid_nums)
+                                      valid_nums.stop_index, t_max=t_max), True
+        padded = torch.nn.utils.rnn.pad_sequence(list(valid_nums))
+        if t_max is not None and padded.shape[0] < t_max:
+            padded = torch.cat([padded, padded.new_zeros(t_max - padded.shape[0], padded.shape[1])])
+        return padded, False
 
     def get_reward(self, valid_smiles, target):
         if self.reward_fn is None:
@@ -294,13 +503,35 @@ class Reinforce(object):
     def _evaluate(self, latent_z, target, return_latent, remove_invalid):
         """Sampling-only entry shared by generate_compounds_and_evaluate of the subclasses
         (reinforce_omics.py:164-180, reinforce_proteins.py:180-198): decode, then score the valid
-        molecules with the host-side ``score_fn`` (the predictor forward is out of scope)."""
-        self._seq_base = 0     # evaluation is not sharded: every rank decodes the whole batch
-        valid_smiles, valid_nums, _ = self.get_smiles_from_latent(latent_z, remove_invalid=remove_invalid)
+        molecules with the host-side ``score_fn`` (the predictor forward is out of scope).
+
+        With a process group the evaluation batch is sharded like a training batch: a rank decodes
+        and scores its contiguous slice (global-row Philox counters, so the molecules are those of the
+        unsharded call), then the (SMILES, prediction) lists are gathered in rank order and every rank
+        returns the whole result.  Random latents (target None) are rank 0's, broadcast."""
+        rank, world = self._dp_rank_world()
         score_fn = getattr(self, 'score_fn', None) or self.reward_fn
         if score_fn is None:
             raise RuntimeError('no scoring function: pass score_fn= or reward_fn=')
+        local = latent_z
+        self._seq_base = 0
+        if world > 1:
+            if target is None:
+                dp.broadcast_(latent_z, src=0, group=self.process_group)
+            lo, hi = dp.shard_range(latent_z.shape[1], rank, world)
+            local = latent_z[:, lo:hi]
+            self._seq_base = lo
+        try:
+            valid_smiles, _, _ = self.get_smiles_from_latent(local, remove_invalid=remove_invalid)
+        finally:
+            self._seq_base = 0
         preds = np.asarray(score_fn(valid_smiles, target)) if len(valid_smiles) else np.zeros(0)
+        if world > 1:
+            import torch.distributed as dist
+            parts = [None] * world
+            dist.all_gather_object(parts, (list(valid_smiles), preds.tolist()), group=self.process_group)
+            valid_smiles = [s for p in parts for s in p[0]]
+            preds = np.asarray([x for p in parts for x in p[1]])
         if return_latent:
             return valid_smiles, preds, latent_z
         return valid_smiles, preds
@@ -436,6 +667,16 @@ class ReinforceMultiModalSets(Reinforce):
         """reinforce_sets.py:438-502."""
         latent_z = self.encode_set(cell_line, protein, self._local_batch(batch_size))
         return self._policy_gradient(latent_z, (protein, cell_line))
+
+
+class _Slice:
+    """One micro-batch of a pipelined step in flight (Reinforce._policy_gradient_pipelined)."""
+
+    def __init__(self, lo, hi, tokens, lens, det, event):
+        import threading
+        self.lo, self.hi, self.tokens, self.lens, self.det, self.event = lo, hi, tokens, lens, det, event
+        self.v_done, self.r_done = threading.Event(), threading.Event()
+        self.valid, self.smiles, self.rewards, self.max_len, self.n_ok = [], [], np.zeros(0, dtype=np.float32), -2, 0
 
 
 class StopRows:
