@@ -117,11 +117,8 @@ class Generator(nn.Module):
         self._philox_offset = 0
 
     def generate_tokens(self, latent_z, prime_input, end_token, generate_len=100, search=None,
-                        seq_index_base: int = 0, early_exit: bool = True, advance: bool = True):
-        """Device-side result: (tokens [B,generate_len], lengths [B]).  ``advance=False`` leaves the
-        Philox offset where it is: the slices of ONE batch decoded by several calls (micro-batches of
-        a pipelined step) share the offset of that batch and differ in ``seq_index_base`` only; the
-        caller advances once with ``skip_draws``."""
+                        seq_index_base: int = 0, early_exit: bool = True):
+        """Device-side result: (tokens [B,generate_len], lengths [B])."""
         temperature = getattr(search, 'temperature', 1.0) if search is not None else 1.0
         if search is not None and getattr(search, 'greedy', False):
             temperature = 0.0
@@ -132,16 +129,14 @@ class Generator(nn.Module):
         dev = self.decoder.output_layer.weight.device
         latent = latent_z.to(dev)
         if latent.shape[-2] == 0:      # empty shard of a data-parallel batch: nothing to decode
-            if advance:
-                self.skip_draws(generate_len)
+            self.skip_draws(generate_len)
             return (torch.zeros(0, int(generate_len), dtype=torch.int64, device=dev),
                     torch.zeros(0, dtype=torch.int32, device=dev))
         tokens, lens = ops.decode(self.decoder.weights(), latent, start, stop, int(generate_len),
                                   temperature=float(temperature), seed=self._philox_seed,
                                   offset=self._philox_offset, seq_index_base=seq_index_base,
                                   early_exit=early_exit)
-        if advance:
-            self._philox_offset += int(generate_len)
+        self._philox_offset += int(generate_len)
         return tokens, lens
 
     def skip_draws(self, generate_len: int) -> None:

@@ -410,6 +410,46 @@ def _reinforce_backward(ctx, g_loss, g_logp, g_gh0, g_grads):
 _reinforce_loss_op.register_autograd(_reinforce_backward, setup_context=_reinforce_setup)
 
 
+class TrainSlice:
+    """The training pair of ONE slice of a batch with the two halves callable apart, on the stream
+    that is current when they are called: construction runs pmg_logprob_fwd (it needs the tokens and
+    h0 only), ``backward(reward, scale)`` runs pmg_reinforce_bwd once the rewards exist.  Workspace and
+    gradient buffers are the slice's own, so slices on different streams share nothing.  No autograd:
+    the caller sums ``grads`` over its slices and feeds ``grad_h0`` to the graph that produced h0.
+    The rows of a slice must fit one workspace (it is one chunk)."""
+
+    def __init__(self, weights: DecoderWeights, tokens: Tensor, h0: Tensor):
+        self.params = [p.detach() for p in weights.flat()]
+        d = self.d = _dims_of(self.params, weights.dims['D'], weights.pad_idx)
+        self.tokens = tokens.to(torch.int64).contiguous()
+        self.h0 = h0.detach().to(torch.float32).contiguous()
+        T, B = _check_train_inputs(self.tokens, self.h0, d)
+        self.shape = _shape(d, B, T)
+        dev = self.h0.device
+        self.ws = _alloc_ws(self.shape, _ffi.PMG_MODE_TRAIN, dev)
+        self.wstruct, self._keep = _wstruct(self.params, d['L'])
+        self.logp = torch.empty(T - 1, B, dtype=torch.float32, device=dev)
+        _fwd_call(self.shape, self.wstruct, self.tokens, self.h0, self.logp, self.ws)
+        self.grads = self.grad_h0 = self.loss = None
+
+    def backward(self, reward: Tensor, scale: float) -> None:
+        d, dev = self.d, self.h0.device
+        B = self.h0.shape[1]
+        self.reward = reward.detach().to(torch.float32).reshape(-1).contiguous()
+        if self.reward.numel() != B:
+            raise _ffi.PmgError('pmg: one reward per sequence required')
+        self.grads = [torch.empty_like(p, dtype=torch.float32) for p in self.params]
+        gstruct, keep = _grad_struct(self.grads, d['L'])
+        self.grad_h0 = torch.empty(d['L'], B, d['H'], dtype=torch.float32, device=dev)
+        self.loss = torch.empty(1, dtype=torch.float32, device=dev)
+        rc = _ffi.lib.pmg_reinforce_bwd(C.byref(self.shape), C.byref(self.wstruct), _ffi._ptr(self.tokens),
+                                        _ffi._ptr(self.reward), float(scale), 0, C.byref(gstruct),
+                                        _ffi._ptr(self.grad_h0), _ffi._ptr(self.loss), _ffi._ptr(self.ws),
+                                        _ffi.current_stream())
+        _ffi.check(rc, 'pmg_reinforce_bwd')
+        del keep
+
+
 def check_token_range(tokens: Tensor, V: int) -> None:
     """Host-side validation of token ids (one device->host round trip): the kernels only clamp."""
     if tokens.numel() == 0:
@@ -480,11 +520,8 @@ class TokenTable:
         self.device = torch.device(device)
         self._out: Dict[tuple, tuple] = {}
 
-    def buffers(self, B: int, max_len: int, fresh: bool = False):
+    def buffers(self, B: int, max_len: int):
         cap = B * max_len * self.max_tok_bytes
-        if fresh:       # several batches in flight at once (micro-batches of a pipelined step)
-            return (torch.empty(B + 1, dtype=torch.int64, device=self.device),
-                    torch.empty(cap, dtype=torch.uint8, device=self.device))
         key = (B, max_len)
         buf = self._out.get(key)
         if buf is None:
@@ -496,10 +533,10 @@ class TokenTable:
 
 
 @torch.no_grad()
-def detokenize_device(table: TokenTable, tokens: Tensor, lens: Tensor, fresh: bool = False):
+def detokenize_device(table: TokenTable, tokens: Tensor, lens: Tensor):
     """Stream-ordered, no synchronisation: (out_off [B+1] int64, out_bytes uint8) on the device;
     row b is out_bytes[out_off[b]:out_off[b+1]].  The buffers belong to ``table`` and are reused by
-    the next call with the same (B, max_len), unless ``fresh`` asks for buffers of the call's own."""
+    the next call with the same (B, max_len)."""
     if tokens.dtype != torch.int64 or lens.dtype != torch.int32:
         raise _ffi.PmgError('pmg_detokenize: tokens must be int64 and lens int32')
     tokens = tokens.contiguous()
@@ -507,7 +544,7 @@ def detokenize_device(table: TokenTable, tokens: Tensor, lens: Tensor, fresh: bo
     B, N = tokens.shape
     if lens.numel() != B:
         raise _ffi.PmgError('pmg_detokenize: one length per row required')
-    out_off, out_bytes = table.buffers(B, N, fresh)
+    out_off, out_bytes = table.buffers(B, N)
     _detokenize_op(tokens, lens, table.tab_off, table.tab_bytes, table.max_tok_bytes, out_off, out_bytes)
     return out_off, out_bytes
 
@@ -517,12 +554,7 @@ def detokenize(table: TokenTable, tokens: Tensor, lens: Tensor) -> List[str]:
     (reinforce.py:172-176): one device pass, two device->host copies, B string slices."""
     if tokens.shape[0] == 0:
         return []
-    return detokenize_collect(table, *detokenize_device(table, tokens, lens))
-
-
-def detokenize_collect(table: TokenTable, out_off: Tensor, out_bytes: Tensor) -> List[str]:
-    """Host half of ``detokenize``: two device->host copies on the CURRENT stream (a pipelined caller
-    runs it on a side stream that waits for this batch only) and B string slices."""
+    out_off, out_bytes = detokenize_device(table, tokens, lens)
     off = out_off.cpu().tolist()
     blob = out_bytes[:off[-1]].cpu().numpy().tobytes()
     if table.ascii:

@@ -49,8 +49,9 @@ class Reinforce(object):
         reward_fn:     host reward ``f(smiles, target) -> array`` (reinforce_omics.py:209-222)
         score_fn:      host scoring used by generate_compounds_and_evaluate (defaults to reward_fn)
         process_group: torch.distributed group for data-parallel latent sharding
-        micro_batches: k > 1 pipelines the host scoring of a step against its GPU work (see
-                       _policy_gradient_pipelined); also read from params['micro_batches']; default 1
+        micro_batches: k > 1 runs the reward scoring of a step under its teacher-forced pass and the
+                       backward passes of earlier slices (_policy_gradient_pipelined); also read from
+                       params['micro_batches']; default 1 (the reference's serial order)
         """
         super(Reinforce, self).__init__()
         self.generator = generator
@@ -79,7 +80,7 @@ class Reinforce(object):
         self.score_fn = score_fn
         self.process_group = process_group
         self.micro_batches = max(1, int(micro_batches if micro_batches is not None else params.get('micro_batches', 1)))
-        self._side_stream = None
+        self._streams = []      # one per slice of a pipelined step
 
         # reinforce.py:59-77
         if params.get('save_untrained', True):
@@ -133,8 +134,7 @@ class Reinforce(object):
         self._seq_base = lo
         return hi - lo
 
-    def sample_tokens(self, latent, seq_index_base: Optional[int] = None, early_exit: bool = True,
-                      advance: bool = True):
+    def sample_tokens(self, latent, seq_index_base: Optional[int] = None, early_exit: bool = True):
         """Device-side half of get_smiles_from_latent: (tokens [B,generate_len], lengths [B])."""
         if seq_index_base is None:
             seq_index_base = getattr(self, '_seq_base', 0)
@@ -145,7 +145,7 @@ class Reinforce(object):
             end_token=torch.Tensor([lang.stop_index]).long(),
             generate_len=self.generate_len,
             search=SamplingSearch(temperature=self.temperature),
-            seq_index_base=seq_index_base, early_exit=early_exit, advance=advance)
+            seq_index_base=seq_index_base, early_exit=early_exit)
 
     def _token_table(self, lang):
         """Device table for pmg_detokenize when the language exposes ``index_to_token`` (pytoda's
@@ -295,179 +295,104 @@ class Reinforce(object):
         return r, float(loss)
 
     # ------------------------------------------------------------------ pipelined step
-    def _sample_device(self, latent, seq_index_base: int, advance: bool = True, fresh: bool = False):
-        """Device half of get_smiles_from_latent, stream-ordered, no synchronisation: decode and -- for a
-        language with ``index_to_token`` -- the detokeniser launches.  Returns (tokens, lens, det) with
-        det = (out_off, out_bytes) on the device, or None."""
-        tokens, lens = self.sample_tokens(latent, seq_index_base=seq_index_base, advance=advance)
-        table = self._token_table(self.generator.smiles_language)
-        det = None
-        if table is not None and tokens.shape[0] > 0:
-            det = ops.detokenize_device(table, tokens, lens, fresh=fresh)
-        return tokens, lens, det
-
-    def _host_strings(self, tokens, lens, det):
-        """Host half: the molecule strings of a decoded batch (blocking device->host copies on the
-        CURRENT stream), reinforce.py:172-176."""
-        lang = self.generator.smiles_language
-        if tokens.shape[0] == 0:
-            return []
-        if det is not None:
-            return ops.detokenize_collect(self._token_table(lang), *det)
-        tok, ln = tokens.cpu(), lens.cpu().tolist()
-        return [lang.token_indexes_to_smiles(tok[r, :ln[r]].tolist()) for r in range(tok.shape[0])]
-
     def _policy_gradient_pipelined(self, latent_z, target):
-        """One REINFORCE step (reinforce_omics.py:289-342) whose host scoring runs UNDER its GPU work.
+        """One REINFORCE step (reinforce_omics.py:289-342) with the reward scoring of the host running
+        UNDER the GPU work that does not depend on it.
 
-        The reference is serial: decode all -> detokenise / SELFIES / RDKit validity all
-        (reinforce.py:172-211) -> reward all (reinforce_omics.py:300) -> teacher-forced loop + backward.
-        With a process pool behind ``is_valid_batch`` / ``reward_fn`` the host stages cost about as much
-        as the GPU ones at B = 4096, so the batch is cut into ``micro_batches`` contiguous slices:
+        The reference is serial: decode (D) -> strings + validity (V, reinforce.py:172-211) -> reward
+        (R, reinforce_omics.py:300) -> teacher-forced pass (T) -> backward (B: BPTT, W: weight
+        gradients).  What can overlap is set by two facts.  (i) D -> V -> R -> B is a true dependency
+        chain: validity needs the molecules, T_max (the longest VALID molecule, to which every row is
+        padded without a mask, reinforce_omics.py:304,322-332) needs every validity, the backward pass
+        needs the rewards.  (ii) The persistent kernels own 16 sequences per workgroup for all time
+        steps, so their duration is (steps x step latency) whatever the batch: a slice of the batch is
+        not faster than the whole, slices only run side by side on disjoint CUs.  Cutting D or V into
+        slices therefore buys nothing (measured: profiles/r03_harness.json, first form).  What is off
+        the chain is T -- it needs validity but not the rewards -- and, for all but the last slice, B
+        and W.  So, with k = ``micro_batches`` slices of the VALID molecules:
 
-          GPU  : D0 D1 .. Dk-1 |            L0   L1  ..  Lk-1        D = decode (+ detokeniser launches)
-          host :    V0 V1  ..  Vk-1 | R0   R1   ..   Rk-1             V = strings + validity, R = reward
-                                                                     L = teacher-forced pass + BPTT + weight gradients
-        Why two phases and not one: ``pad_sequence`` pads to the longest VALID molecule of the whole
-        batch and the padded positions are not masked (reinforce_omics.py:304,322-332), so every row's
-        loss depends on T_max, which is known only when every slice's validity is.  Validity therefore
-        overlaps the decodes, the rewards overlap the backward passes, and the GPU idles only for the
-        last slice's validity and the first slice's reward (1/k of each).
+          GPU  : D | idle (V) | T0..Tk-1 side by side | B0 W0 | B1 W1 | .. | Bk-1 Wk-1 |   clip, Adam
+          host :   |    V     | R0      R1      ..        Rk-1 |
+                                (slice i's backward is queued on stream i the moment R_i returns)
 
-        Same results as the serial step: Philox counters are keyed by the global row and all slices share
-        the step's offset, so the tokens are identical; the gradients of the slices accumulate (the loss
-        is a sum over molecules; scale = 1 / valid molecules of the whole batch, known before the first
-        backward pass); T_max is the batch's; clip + Adam run once.  The encoder is differentiated once,
-        through the summed latent gradient of the slices."""
-        import threading
-        gen, dec, dev = self.generator, self.generator.decoder, self.device
-        lang = gen.smiles_language
-        B_local = latent_z.shape[1]
-        k = min(self.micro_batches, B_local)
-        base = getattr(self, '_seq_base', 0)
-        self._seq_base = 0
+        Every slice has its own stream, workspace and gradient buffers; the streams join before the
+        gradients are summed.  Same result as the serial step: same molecules (the decode is the serial
+        one), same T_max, loss and gradients are sums over molecules with scale = 1 / valid molecules of
+        the whole batch; the encoder and latent_to_hidden are differentiated once, through the
+        concatenated hidden-state gradient of the slices."""
+        dec, dev = self.generator.decoder, self.device
         ddp = self.process_group is not None
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=dev)
-        side = self._side_stream
-
-        # ---- phase 1, GPU: every slice's decode is queued now; an event marks the end of each
-        slices = []
-        with torch.no_grad():
-            lat = latent_z.detach()
-            for i in range(k):
-                lo, hi = dp.shard_range(B_local, i, k)
-                tokens, lens, det = self._sample_device(lat[:, lo:hi], base + lo, advance=False, fresh=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                slices.append(_Slice(lo, hi, tokens, lens, det, ev))
-        gen.skip_draws(self.generate_len)       # one batch, one advance of the Philox offset
-        err = []
-
-        def host_worker():
-            # validity of a slice as soon as its decode has finished (T_max needs all of them); rewards
-            # fill the time the host would otherwise wait for a decode, and follow in slice order
-            try:
-                nv = nr = 0
-                with torch.cuda.stream(side):
-                    while nr < k:
-                        if nv < k and (nr >= nv or slices[nv].event.query()):
-                            s = slices[nv]
-                            side.wait_event(s.event)        # copies of this slice wait for its decode only
-                            strings = self._host_strings(s.tokens, s.lens, s.det)
-                            smiles = [lang.selfies_to_smiles(x) for x in strings]
-                            ok = self._validity(smiles)
-                            s.n_ok = sum(ok)
-                            s.valid = [j for j in range(len(ok)) if ok[j]]
-                            s.smiles = [smiles[j] for j in s.valid]
-                            ln = s.lens.cpu().tolist()
-                            s.max_len = max((ln[j] for j in s.valid), default=-2)
-                            s.v_done.set()
-                            nv += 1
-                        else:
-                            s = slices[nr]
-                            s.rewards = np.asarray(self.get_reward(s.smiles, target), dtype=np.float32).reshape(-1) \
-                                if s.valid else np.zeros(0, dtype=np.float32)
-                            if s.rewards.shape[0] != len(s.valid):
-                                raise RuntimeError('reward_fn must return one reward per molecule')
-                            s.r_done.set()
-                            nr += 1
-            except BaseException as e:      # handed to the main thread, which re-raises
-                err.append(e)
-            finally:
-                for s in slices:
-                    s.v_done.set()
-                    s.r_done.set()
-
-        th = threading.Thread(target=host_worker, name='pmg-host-scoring', daemon=True)
-        th.start()
-
-        def wait(flag):
-            flag.wait()
-            if err:
-                th.join()
-                raise err[0]
-
-        for s in slices:
-            wait(s.v_done)
-        n_valid = sum(len(s.valid) for s in slices)
-        if self.logger is not None:
-            self.logger.info(f'{self.model_name}: SMILES validity: {100.0 * n_valid / max(1, B_local):.2f}%.')
-        t_max = max(s.max_len for s in slices) + 2
-        if ddp:
-            t_max = dp.global_max(t_max, dev, self.process_group)
+        try:
+            valid_smiles, valid_nums, valid_idx = self.get_smiles_from_latent(latent_z, remove_invalid=True)
+        finally:
+            self._seq_base = 0
+        n_valid = len(valid_nums)
         if n_valid == 0:
             if self.logger is not None:
                 self.logger.warning('no valid molecule in the batch' + (' of this rank' if ddp else ': update skipped'))
             if not ddp:
-                th.join()
                 return torch.tensor(0.0), 0.0
-
-        # ---- phase 2: slice i is back-propagated as soon as its rewards are in
-        lrps = self._lrps()
-        enc_params = list(self.encoder.parameters()) if self.encoder is not None else []
+        t_max = self._local_t_max(valid_nums, valid_idx)
+        if ddp:
+            t_max = dp.global_max(t_max, dev, self.process_group)
         dec_params = list(dec.parameters())
-        leaf = latent_z.detach().to(dev)
-        if latent_z.requires_grad:
-            leaf.requires_grad_(True)
+        enc_params = list(self.encoder.parameters()) if self.encoder is not None else []
+        rewards_all = []
 
         def run(scale):
-            total = torch.zeros((), dtype=torch.float32, device=dev)
-            for s in slices:
-                wait(s.r_done)
-                if not s.valid:
-                    continue
-                idx = torch.as_tensor(s.valid, dtype=torch.long, device=dev)
-                padded = pad_rows_on_device(s.tokens.index_select(0, idx), s.lens.index_select(0, idx),
-                                            lang.stop_index, t_max=t_max)
-                dec._update_batch_size(len(s.valid))
-                hidden = dec.latent_to_hidden(leaf.repeat(dec.n_layers, 1, lrps)[:, idx + s.lo, :])
-                r_t = torch.from_numpy(s.rewards).to(dev)
-                loss, _ = ops.reinforce_loss(dec.weights(), padded, hidden, r_t, scale, trusted_tokens=True)
-                loss.backward()
-                total = total + loss.detach()
-            if leaf.grad is not None:       # the encoder is differentiated once (reinforce_omics.py:87,313)
-                latent_z.backward(leaf.grad.to(latent_z.device))
-            return total
+            padded, trusted = self._padded_valid(valid_nums, valid_idx, t_max)
+            padded = padded.to(dev)
+            if not trusted:
+                ops.check_token_range(padded, dec.vocab_size)
+            # slices: whole 16-sequence row groups, at most one slice per stream
+            per = -(-(-(-n_valid // self.micro_batches)) // 16) * 16
+            bounds = [(lo, min(n_valid, lo + per)) for lo in range(0, n_valid, per)]
+            while len(self._streams) < len(bounds):
+                self._streams.append(torch.cuda.Stream(device=dev))
+            dec._update_batch_size(n_valid)
+            idx = valid_idx if torch.is_tensor(valid_idx) else torch.as_tensor(valid_idx, dtype=torch.long)
+            hidden = dec.latent_to_hidden(latent_z.to(dev).repeat(dec.n_layers, 1, self._lrps())[:, idx.to(dev), :])
+            weights = dec.weights()
+            main = torch.cuda.current_stream()
+            ready = main.record_event()
+            jobs = []
+            for (lo, hi), st in zip(bounds, self._streams):      # T_i: needs validity and T_max, not the rewards
+                st.wait_event(ready)
+                with torch.cuda.stream(st):
+                    jobs.append(ops.TrainSlice(weights, padded[:, lo:hi], hidden.detach()[:, lo:hi]))
+            for (lo, hi), st, job in zip(bounds, self._streams, jobs):
+                r = np.asarray(self.get_reward(valid_smiles[lo:hi], target), dtype=np.float32).reshape(-1)
+                if r.shape[0] != hi - lo:
+                    raise RuntimeError('reward_fn must return one reward per molecule')
+                rewards_all.append(r)
+                r_t = torch.from_numpy(r).to(dev)       # on the (idle) main stream: never waits for T_i
+                st.wait_event(main.record_event())
+                with torch.cuda.stream(st):
+                    job.backward(r_t, scale)
+            for st in self._streams[:len(bounds)]:
+                main.wait_stream(st)
+            grads = jobs[0].grads
+            for job in jobs[1:]:
+                torch._foreach_add_(grads, job.grads)
+            for p, g in zip(weights.flat(), grads):
+                p.grad = g if p.grad is None else p.grad.add_(g)
+            hidden.backward(torch.cat([job.grad_h0 for job in jobs], dim=1))    # latent_to_hidden, encoder
+            loss = jobs[0].loss
+            for job in jobs[1:]:
+                loss = loss + job.loss
+            return loss.reshape(())
 
-        def reward_sum():
-            return float(sum(float(s.rewards.sum(dtype=np.float64)) for s in slices))
-
-        try:
-            if ddp:
-                r, loss, _ = dp.data_parallel_step(dec_params, enc_params, self.optimizer, lambda: run(1.0), n_valid,
-                                                   reward_sum, self.grad_clipping, group=self.process_group)
-            else:
-                self.optimizer.zero_grad()
-                loss = run(1.0 / n_valid)
-                r = torch.mean(torch.from_numpy(np.concatenate([s.rewards for s in slices])).float())
-                if self.grad_clipping is not None:
-                    torch.nn.utils.clip_grad_norm_(dec_params + enc_params, self.grad_clipping)
-                self.optimizer.step()
-        finally:
-            th.join()
-        if err:
-            raise err[0]
+        if ddp:
+            r, loss, _ = dp.data_parallel_step(dec_params, enc_params, self.optimizer, lambda: run(1.0), n_valid,
+                                               lambda: float(sum(float(x.sum(dtype=np.float64)) for x in rewards_all)),
+                                               self.grad_clipping, group=self.process_group)
+            return r, float(loss)
+        self.optimizer.zero_grad()
+        loss = run(1.0 / n_valid)
+        r = torch.mean(torch.from_numpy(np.concatenate(rewards_all)).float())
+        if self.grad_clipping is not None:
+            torch.nn.utils.clip_grad_norm_(dec_params + enc_params, self.grad_clipping)
+        self.optimizer.step()
         return r, float(loss)
 
     @staticmethod
@@ -667,16 +592,6 @@ class ReinforceMultiModalSets(Reinforce):
         """reinforce_sets.py:438-502."""
         latent_z = self.encode_set(cell_line, protein, self._local_batch(batch_size))
         return self._policy_gradient(latent_z, (protein, cell_line))
-
-
-class _Slice:
-    """One micro-batch of a pipelined step in flight (Reinforce._policy_gradient_pipelined)."""
-
-    def __init__(self, lo, hi, tokens, lens, det, event):
-        import threading
-        self.lo, self.hi, self.tokens, self.lens, self.det, self.event = lo, hi, tokens, lens, det, event
-        self.v_done, self.r_done = threading.Event(), threading.Event()
-        self.valid, self.smiles, self.rewards, self.max_len, self.n_ok = [], [], np.zeros(0, dtype=np.float32), -2, 0
 
 
 class StopRows:

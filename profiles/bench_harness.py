@@ -79,7 +79,7 @@ def pipelined(B, out, pools):
     t0 = time.perf_counter()
     pv(['C' * 10] * B)
     res['host_validity_stage_ms'] = round((time.perf_counter() - t0) * 1e3, 2)     # B molecules through the pool
-    for k in (1, 2, 4, 8, 16):
+    for k in (1, 2, 4, 8):
         dec = StackGRUDecoder(dict(vocab_size=V)).cuda()
         enc = Enc().cuda()
         gen = Generator(enc, dec)

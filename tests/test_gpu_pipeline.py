@@ -1,12 +1,12 @@
 """Host scoring pipelined against the GPU work of one policy_gradient step (SURVEY.md section 8 f1,
 second half; Reinforce._policy_gradient_pipelined).  The reference runs decode -> validity -> reward
 -> teacher-forced loop + backward strictly one after the other (reinforce.py:162-211,
-reinforce_omics.py:295-341); with ``micro_batches=k`` the batch is decoded, scored and back-propagated
-in k slices whose host stages run under the GPU stages of the neighbouring slices.  The result must be
-that of the serial step: the same molecules, the same (mean reward, loss), gradients within 1e-6."""
+reinforce_omics.py:295-341); with ``micro_batches=k`` the valid molecules are cut into k slices: their
+teacher-forced passes run side by side on k streams while the host computes the rewards slice by slice,
+and a slice's backward pass is queued the moment its rewards exist.  The result must be that of the
+serial step: the same molecules, the same (mean reward, loss), gradients within 1e-6."""
 import copy
 import logging
-import threading
 
 import numpy as np
 import pandas as pd
@@ -19,7 +19,7 @@ from tests.test_gpu_harness import ALPHABET, FakeEncoder, FakeLanguage, reward_f
 pytestmark = pytest.mark.gpu
 PARAMS = dict(P.TINY, latent_dim=32)
 HP = dict(generate_len=14, temperature=0.9, clip_grad=0.1, learning_rate=1e-3, save_untrained=False)
-BATCH = 52        # k = 4: slices of 13 rows; rows 13..25 (slice 1) are all invalid
+BATCH = 100       # about 58 valid molecules: four slices of 16 rows at k = 4
 
 
 class TableLanguage(FakeLanguage):
@@ -36,19 +36,18 @@ def _build(k, language, seed=0):
     gen.seed(33)
     rng = np.random.RandomState(0)
     df = pd.DataFrame({'cell_line': ['cl0'], 'gene_expression': [pd.Series(rng.randn(9).astype(np.float32))]})
-    state = dict(cursor=0, seen=[], threads=set(), reward_calls=0)
+    state = dict(cursor=0, seen=[], reward_sizes=[])
 
     def is_valid_batch(smiles):
         # called per step (serial) or per slice in row order: the cursor is the first row of the call
         base = state['cursor']
         state['cursor'] += len(smiles)
         state['seen'].extend(smiles)
-        state['threads'].add(threading.current_thread().name)
         return [len(s) > 0 and (s.count('C') + s.count('N') + base + i) % 3 != 0 and not (13 <= base + i < 26)
                 for i, s in enumerate(smiles)]
 
     def reward(smiles, target):
-        state['reward_calls'] += 1
+        state['reward_sizes'].append(len(smiles))
         return reward_fn(smiles, target)
 
     learner = ReinforceOmic(gen, enc, None, df, dict(HP), 'm', logging.getLogger('pipe'), reward_fn=reward,
@@ -74,12 +73,13 @@ def _two_steps(k, language):
 @pytest.mark.parametrize('language', [TableLanguage, FakeLanguage], ids=['device_detok', 'host_rows'])
 def test_micro_batches_equal_the_serial_step(gpu, language):
     ref, g_dec, g_enc, w_dec, st1 = _two_steps(1, language)
-    assert st1['threads'] == {'MainThread'}
+    n_valid = st1['reward_sizes'][0]
+    assert len(st1['reward_sizes']) == 2 and 48 < n_valid <= 64
     for k in (2, 4):
         out, gd, ge, wd, st = _two_steps(k, language)
         assert st['seen'] == st1['seen'], k                      # identical molecules, in order
-        assert st['threads'] == {'pmg-host-scoring'}             # scored off the main thread
-        assert st['reward_calls'] == 2 * (k - (1 if k == 4 else 0))   # an all-invalid slice is not scored
+        sizes = st['reward_sizes'][:len(st['reward_sizes']) // 2]      # first step: one reward call per slice
+        assert len(sizes) == k and sum(sizes) == n_valid and all(n % 16 == 0 for n in sizes[:-1]), sizes
         for (r, l), (r1, l1) in zip(out, ref):
             assert r == r1                                       # same rewards, same order, same mean
             assert abs(l - l1) <= 1e-6 * abs(l1), (k, l, l1)
@@ -118,7 +118,7 @@ def test_pipelined_step_matches_oracle(gpu):
             assert P.rel_err(pp.grad.cpu(), po.grad) < 1e-4, n
 
 
-def test_no_valid_molecule_and_worker_errors(gpu):
+def test_no_valid_molecule_and_reward_errors(gpu):
     learner, state = _build(3, TableLanguage)
     learner.is_valid_batch = lambda smiles: [False] * len(smiles)
     before = torch.cat([p.detach().reshape(-1).clone() for p in learner.generator.decoder.parameters()])
@@ -126,12 +126,19 @@ def test_no_valid_molecule_and_worker_errors(gpu):
     assert (float(r), l) == (0.0, 0.0)
     assert torch.equal(before, torch.cat([p.detach().reshape(-1) for p in learner.generator.decoder.parameters()]))
 
-    def boom(smiles):
-        raise ValueError('validity backend died')
-    learner.is_valid_batch = boom
-    with pytest.raises(ValueError, match='validity backend died'):
-        learner.policy_gradient('cl0', 1, BATCH)
-    # and the learner is usable afterwards
+    calls = []
+
+    def boom(smiles, target):      # the second slice's reward fails while the first slice's backward is in flight
+        calls.append(len(smiles))
+        if len(calls) == 2:
+            raise ValueError('reward backend died')
+        return reward_fn(smiles, target)
     learner.is_valid_batch = lambda smiles: [True] * len(smiles)
+    learner.reward_fn = boom
+    with pytest.raises(ValueError, match='reward backend died'):
+        learner.policy_gradient('cl0', 1, BATCH)
+    torch.cuda.synchronize()
+    # and the learner is usable afterwards
+    learner.reward_fn = reward_fn
     r, l = learner.policy_gradient('cl0', 1, BATCH)
     assert np.isfinite(l) and l != 0.0
