@@ -201,15 +201,16 @@ def time_phases(learner, cfg, latent, rewards, B, reps=3):
         _ffi.check(_ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(h0),
                                             _ffi._ptr(logp), None, 0, _ffi._ptr(ws), st), 'fwd')
 
-    def f_bwd(flags):
-        def f():
-            _ffi.check(_ffi.lib.pmg_reinforce_bwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded),
-                                                  _ffi._ptr(rewards), 1.0 / B, flags, C.byref(gstruct),
-                                                  _ffi._ptr(gh0), _ffi._ptr(loss), _ffi._ptr(ws), st), 'bwd')
-        return f
+    def f_bptt():
+        _ffi.check(_ffi.lib.pmg_reinforce_bptt(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(rewards),
+                                               1.0 / B, _ffi._ptr(gh0), _ffi._ptr(ws), st), 'bptt')
+
+    def f_wgrad():
+        _ffi.check(_ffi.lib.pmg_reinforce_wgrad(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), 0,
+                                                C.byref(gstruct), _ffi._ptr(loss), _ffi._ptr(ws), st), 'wgrad')
     out['teacher_fwd'] = timed(f_fwd)
-    out['bptt'] = timed(f_bwd(_ffi.PMG_FLAG_SKIP_WGRAD))
-    out['wgrad'] = timed(f_bwd(_ffi.PMG_FLAG_ONLY_WGRAD))
+    out['bptt'] = timed(f_bptt)
+    out['wgrad'] = timed(f_wgrad)
     out['_steps'] = dict(decode=T, teacher_fwd=Tt - 1, bptt=Tt - 1, wgrad=Tt - 1)
     out['_batch'] = B
     del ws
@@ -334,6 +335,17 @@ def main():
         dp.all_reduce_(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
+    replicas_identical = None
+    if pg is not None:
+        # replicas must still be identical after the steps (no broadcast is ever done)
+        flat = torch.cat([p.detach().reshape(-1) for p in learner.generator.decoder.parameters()])
+        lo, hi = flat.clone(), flat.clone()
+        dp.all_reduce_(lo, op=dist.ReduceOp.MIN)
+        dp.all_reduce_(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(torch.equal(lo, hi))
+        if not replicas_identical:
+            raise SystemExit(f'rank {rank}: decoder replicas diverged')
+
     ms_per_step = 1e3 * el / args.steps
     tokens_per_s = world * tokens_per_step * args.steps / el
     F = flops_per_token(cfg)
@@ -355,6 +367,8 @@ def main():
         'step_executed_flop_frac': (tokens_per_s / world) * (3 if args.config == 'cfg5' else 4) * F /
                                    (PEAK_F32_MFMA_TFLOPS * 1e12),
         'tokens_per_step_per_gpu': tokens_per_step,
+        'replicas_identical': replicas_identical,     # N>1: checked over all ranks after the timed steps
+        'dist_backend': (dist.get_backend(pg) if pg is not None else None),
     }
     if rank == 0:
         if not args.no_phases:
@@ -373,13 +387,6 @@ def main():
             result['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(result), flush=True)
     if pg is not None:
-        # replicas must still be identical after the steps (no broadcast is ever done)
-        flat = torch.cat([p.detach().reshape(-1) for p in learner.generator.decoder.parameters()])
-        lo, hi = flat.clone(), flat.clone()
-        dp.all_reduce_(lo, op=dist.ReduceOp.MIN)
-        dp.all_reduce_(hi, op=dist.ReduceOp.MAX)
-        if not torch.equal(lo, hi):
-            raise SystemExit(f'rank {rank}: decoder replicas diverged')
         dist.barrier()
         dist.destroy_process_group()
 

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define PMG_MAX_LAYERS 4
-#define PMG_ABI_VERSION 2
+#define PMG_ABI_VERSION 3
 
 /* workspace modes */
 #define PMG_MODE_DECODE 0 /* pmg_decode */
@@ -34,9 +34,7 @@ extern "C" {
 
 /* flags */
 #define PMG_FLAG_NO_EARLY_EXIT 1u /* decode: run all gen_len steps even after every row hit stop */
-#define PMG_FLAG_ACCUMULATE 2u    /* bwd: add into grad_out AND loss_out instead of overwriting them (chunked batches) */
-#define PMG_FLAG_SKIP_WGRAD 4u    /* bwd, profiling aid: run the time recurrence only (grad_out untouched) */
-#define PMG_FLAG_ONLY_WGRAD 8u    /* bwd, profiling aid: redo the weight-gradient GEMM of the previous call */
+#define PMG_FLAG_ACCUMULATE 2u    /* bwd / wgrad: add into grad_out AND loss_out instead of overwriting them (chunked batches) */
 #define PMG_FLAG_REUSE_PACK 16u   /* logprob_fwd: `ws` still holds the packed weights of the previous
                                      pmg_logprob_fwd call on it (same weights, same model dimensions; B and T
                                      may differ): skip the packing kernels.  For batches run in chunks. */
@@ -90,9 +88,11 @@ int pmg_abi_version(void);
 /* Text for a negative return code. */
 const char* pmg_strerror(int code);
 
-/* 0 if `s` is a shape the kernels support (H in {128,256,512,1024}, W<=64,
- * 3+W+V<=256, 1<=L<=PMG_MAX_LAYERS, ...); else the error code every entry point
- * would return for it. */
+/* 0 if `s` is a shape the kernels support -- what StackGRUDecoder(params) of the reference's
+ * drivers admits (examples/IC50/train_paccmann_rl.py:93-97) within: H a multiple of 128 in
+ * [128,1024], 1<=W<=64, D>=2, 2<=V<=1024, 1<=L<=PMG_MAX_LAYERS, Z a multiple of 32 (decode), and the
+ * per-workgroup state fitting the CU's 160 KiB of LDS (a very wide vocabulary together with many
+ * layers may not) -- else the error code every entry point would return for it. */
 int pmg_check_shape(const pmg_shape* s, int mode);
 
 /* Bytes of device scratch needed for `mode` at shape `s` (256-byte aligned base). */
@@ -166,6 +166,20 @@ int pmg_reinforce_bwd(const pmg_shape* s, const pmg_weights* w, const int64_t* t
                       const float* reward, float scale, uint32_t flags,
                       const pmg_grads* grad_out, float* grad_h0, float* loss_out,
                       void* ws, pmg_stream stream);
+
+/* The two halves of pmg_reinforce_bwd as entry points of their own (pmg_reinforce_bwd is exactly
+ * pmg_reinforce_bptt followed by pmg_reinforce_wgrad on the same stream), for callers that time or
+ * schedule them apart: the BPTT is a latency-bound recurrence, the weight-gradient GEMM a
+ * throughput-bound contraction over all B*T tokens.
+ *   pmg_reinforce_bptt : walks time backwards from the trajectory pmg_logprob_fwd left in `ws`; writes
+ *                        grad_h0 and, into `ws`, the per-step gate / extras gradient slabs and the
+ *                        loss partials.
+ *   pmg_reinforce_wgrad: contracts those slabs with the saved activations into grad_out (every
+ *                        decoder parameter) and loss_out; flags: 0 or PMG_FLAG_ACCUMULATE. */
+int pmg_reinforce_bptt(const pmg_shape* s, const pmg_weights* w, const int64_t* tokens,
+                       const float* reward, float scale, float* grad_h0, void* ws, pmg_stream stream);
+int pmg_reinforce_wgrad(const pmg_shape* s, const pmg_weights* w, const int64_t* tokens, uint32_t flags,
+                        const pmg_grads* grad_out, float* loss_out, void* ws, pmg_stream stream);
 
 /* One decoder step -- the duck-typed `decoder(tok[1,B], hidden, stack)` call of
  * reinforce_omics.py:323-325 plus `decoder.output_layer` (:326).

@@ -16,10 +16,8 @@ PMG_MODE_DECODE = 0
 PMG_MODE_TRAIN = 1
 PMG_FLAG_NO_EARLY_EXIT = 1
 PMG_FLAG_ACCUMULATE = 2
-PMG_FLAG_SKIP_WGRAD = 4
-PMG_FLAG_ONLY_WGRAD = 8
 PMG_FLAG_REUSE_PACK = 16
-PMG_ABI_VERSION = 2
+PMG_ABI_VERSION = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PMG_LIB selects a tuning variant built by __graft_entry__.build(extra_flags=..., libname=...)
@@ -56,7 +54,7 @@ class PmgGrads(C.Structure):
 EXPORTS = (
     'pmg_abi_version', 'pmg_strerror', 'pmg_check_shape', 'pmg_workspace_bytes',
     'pmg_decode', 'pmg_logprob_fwd', 'pmg_reinforce_bwd', 'pmg_step', 'pmg_detokenize',
-    'pmg_decode_noalloc', 'pmg_noalloc_scratch_bytes',
+    'pmg_decode_noalloc', 'pmg_noalloc_scratch_bytes', 'pmg_reinforce_bptt', 'pmg_reinforce_wgrad',
 )
 
 
@@ -83,6 +81,12 @@ def _load():
     lib.pmg_reinforce_bwd.argtypes = [
         C.POINTER(PmgShape), C.POINTER(PmgWeights), C.c_void_p, C.c_void_p, C.c_float, C.c_uint32,
         C.POINTER(PmgGrads), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.pmg_reinforce_bptt.argtypes = [
+        C.POINTER(PmgShape), C.POINTER(PmgWeights), C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+        C.c_void_p]
+    lib.pmg_reinforce_wgrad.argtypes = [
+        C.POINTER(PmgShape), C.POINTER(PmgWeights), C.c_void_p, C.c_uint32, C.POINTER(PmgGrads), C.c_void_p,
+        C.c_void_p, C.c_void_p]
     lib.pmg_step.argtypes = [
         C.POINTER(PmgShape), C.POINTER(PmgWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

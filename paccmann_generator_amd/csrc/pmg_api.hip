@@ -80,9 +80,9 @@ extern "C" const char* pmg_strerror(int code) {
     case PMG_OK: return "ok";
     case PMG_E_NULL: return "null pointer argument";
     case PMG_E_SHAPE: return "bad shape: need B>=1, T>=1 (train: T>=2), E>=1, D>=2, Z%32==0";
-    case PMG_E_HIDDEN: return "unsupported rnn_cell_size: H must be 128, 256, 512 or 1024";
+    case PMG_E_HIDDEN: return "unsupported rnn_cell_size: H must be a multiple of 128 between 128 and 1024";
     case PMG_E_STACK: return "unsupported stack: need 1<=W<=64, 2<=D";
-    case PMG_E_VOCAB: return "unsupported vocabulary: need 3+W+V<=256";
+    case PMG_E_VOCAB: return "unsupported vocabulary: need 2<=V<=1024";
     case PMG_E_LAYERS: return "unsupported n_layers: need 1<=L<=4";
     case PMG_E_ALIGN: return "pointer not 16-byte aligned (b_l2h of pmg_decode, grad_h0 of pmg_reinforce_bwd)";
     case PMG_E_MODE: return "unknown workspace mode";
@@ -96,10 +96,10 @@ extern "C" const char* pmg_strerror(int code) {
 extern "C" int pmg_check_shape(const pmg_shape* s, int mode) {
   if (!s) return PMG_E_NULL;
   if (mode != PMG_MODE_DECODE && mode != PMG_MODE_TRAIN) return PMG_E_MODE;
-  if (s->H != 128 && s->H != 256 && s->H != 512 && s->H != 1024) return PMG_E_HIDDEN;
+  if (s->H < 128 || s->H > 1024 || s->H % 128 != 0) return PMG_E_HIDDEN;
   if (s->L < 1 || s->L > PMG_MAX_LAYERS) return PMG_E_LAYERS;
   if (s->W < 1 || s->W > PMG_KS || s->D < 2) return PMG_E_STACK;
-  if (s->V < 2 || 3 + s->W + s->V > 256) return PMG_E_VOCAB;
+  if (s->V < 2 || s->V > PMG_MAX_VOCAB) return PMG_E_VOCAB;
   if (s->B < 1 || s->T < 1 || s->E < 1) return PMG_E_SHAPE;
   if (mode == PMG_MODE_TRAIN && s->T < 2) return PMG_E_SHAPE;
   if (mode == PMG_MODE_DECODE && (s->Z < 32 || s->Z % 32 != 0)) return PMG_E_SHAPE;
@@ -107,6 +107,12 @@ extern "C" int pmg_check_shape(const pmg_shape* s, int mode) {
   size_t lds = ((size_t)d.L * 16 * d.HP + 16 * PMG_XTP + (size_t)16 * d.XP + 32) * 4;
   if (mode == PMG_MODE_DECODE) lds += (size_t)16 * (d.Z + 8) * 4;
   if (lds > 160 * 1024) return PMG_E_LDS;
+  if (mode == PMG_MODE_TRAIN) {   // the BPTT needs at least one chunk buffer next to its extras tile
+    BwdArgs b;
+    memset(&b, 0, sizeof(b));
+    b.H = d.H; b.XP = d.XP;
+    if (pmg_bwd_chunk_buffers(&b) < 1) return PMG_E_LDS;
+  }
   return PMG_OK;
 }
 
@@ -338,24 +344,29 @@ extern "C" int pmg_step(const pmg_shape* s, const pmg_weights* w, const int64_t*
   return PMG_OK;
 }
 
-extern "C" int pmg_reinforce_bwd(const pmg_shape* s, const pmg_weights* w, const int64_t* tokens,
-                                 const float* reward, float scale, uint32_t flags, const pmg_grads* grad_out,
-                                 float* grad_h0, float* loss_out, void* ws, pmg_stream stream) {
+// shared argument checks + kernel arguments of the two halves of the backward pass
+static int bwd_setup(const pmg_shape* s, const pmg_weights* w, const int64_t* tokens, void* ws, PmgDims* d,
+                     PmgLayout* lay, float** base) {
   int rc = pmg_check_shape(s, PMG_MODE_TRAIN);
   if (rc) return rc;
-  if (!tokens || !reward || !grad_out || !grad_h0 || !loss_out || !ws) return PMG_E_NULL;
+  if (!tokens || !ws) return PMG_E_NULL;
   if ((rc = check_weights(s, w, false))) return rc;
-  if (!grad_out->embedding || !grad_out->w_ctrl || !grad_out->b_ctrl || !grad_out->w_push || !grad_out->b_push ||
-      !grad_out->w_out || !grad_out->b_out)
-    return PMG_E_NULL;
-  for (int l = 0; l < s->L; ++l)
-    if (!grad_out->w_ih[l] || !grad_out->w_hh[l] || !grad_out->b_ih[l] || !grad_out->b_hh[l]) return PMG_E_NULL;
+  *d = pmg_dims(s);
+  make_layout(*d, PMG_MODE_TRAIN, lay);
+  *base = ws_base(ws);
+  return PMG_OK;
+}
+
+extern "C" int pmg_reinforce_bptt(const pmg_shape* s, const pmg_weights* w, const int64_t* tokens,
+                                  const float* reward, float scale, float* grad_h0, void* ws, pmg_stream stream) {
+  PmgDims d;
+  PmgLayout lay;
+  float* base = nullptr;
+  int rc = bwd_setup(s, w, tokens, ws, &d, &lay, &base);
+  if (rc) return rc;
+  if (!reward || !grad_h0) return PMG_E_NULL;
   if (misaligned16(grad_h0)) return PMG_E_ALIGN;  // written with 16-byte stores
   hipStream_t st = (hipStream_t)stream;
-  const PmgDims d = pmg_dims(s);
-  PmgLayout lay;
-  make_layout(d, PMG_MODE_TRAIN, &lay);
-  float* base = ws_base(ws);
   BwdArgs a;
   memset(&a, 0, sizeof(a));
   a.B = d.B; a.G = d.G; a.N = d.T - 1; a.H = d.H; a.W = d.W; a.D = d.D; a.V = d.V; a.L = d.L;
@@ -373,7 +384,39 @@ extern "C" int pmg_reinforce_bwd(const pmg_shape* s, const pmg_weights* w, const
   a.LP = base + lay.LP;
   a.DX = base + lay.DX; a.DS = base + lay.DS; a.DHC = base + lay.DHC; a.grad_h0 = grad_h0;
   a.LOSSP = base + lay.LOSSP;
-  if (!(flags & PMG_FLAG_ONLY_WGRAD)) HIPCHK(pmg_launch_bwd(&a, st));
-  if (!(flags & PMG_FLAG_SKIP_WGRAD)) HIPCHK(pmg_run_wgrad(d, lay, base, w, tokens, flags, grad_out, loss_out, st));
+  HIPCHK(pmg_launch_bwd(&a, st));
   return PMG_OK;
+}
+
+extern "C" int pmg_reinforce_wgrad(const pmg_shape* s, const pmg_weights* w, const int64_t* tokens, uint32_t flags,
+                                   const pmg_grads* grad_out, float* loss_out, void* ws, pmg_stream stream) {
+  PmgDims d;
+  PmgLayout lay;
+  float* base = nullptr;
+  int rc = bwd_setup(s, w, tokens, ws, &d, &lay, &base);
+  if (rc) return rc;
+  if (!grad_out || !loss_out) return PMG_E_NULL;
+  if (!grad_out->embedding || !grad_out->w_ctrl || !grad_out->b_ctrl || !grad_out->w_push || !grad_out->b_push ||
+      !grad_out->w_out || !grad_out->b_out)
+    return PMG_E_NULL;
+  for (int l = 0; l < s->L; ++l)
+    if (!grad_out->w_ih[l] || !grad_out->w_hh[l] || !grad_out->b_ih[l] || !grad_out->b_hh[l]) return PMG_E_NULL;
+  HIPCHK(pmg_run_wgrad(d, lay, base, w, tokens, flags, grad_out, loss_out, (hipStream_t)stream));
+  return PMG_OK;
+}
+
+extern "C" int pmg_reinforce_bwd(const pmg_shape* s, const pmg_weights* w, const int64_t* tokens,
+                                 const float* reward, float scale, uint32_t flags, const pmg_grads* grad_out,
+                                 float* grad_h0, float* loss_out, void* ws, pmg_stream stream) {
+  // argument errors of either half are reported before anything is launched
+  if (!grad_out || !loss_out || !reward || !grad_h0) return PMG_E_NULL;
+  if (!grad_out->embedding || !grad_out->w_ctrl || !grad_out->b_ctrl || !grad_out->w_push || !grad_out->b_push ||
+      !grad_out->w_out || !grad_out->b_out)
+    return PMG_E_NULL;
+  if (s)
+    for (int l = 0; l < s->L && l < PMG_MAX_LAYERS; ++l)
+      if (!grad_out->w_ih[l] || !grad_out->w_hh[l] || !grad_out->b_ih[l] || !grad_out->b_hh[l]) return PMG_E_NULL;
+  int rc = pmg_reinforce_bptt(s, w, tokens, reward, scale, grad_h0, ws, stream);
+  if (rc) return rc;
+  return pmg_reinforce_wgrad(s, w, tokens, flags, grad_out, loss_out, ws, stream);
 }

@@ -31,7 +31,7 @@
 #define PMG_BWD_AUX_DG 0
 #endif
 
-// Helper waves (H = 512): four extra waves per workgroup, one per SIMD, that never touch the weight
+// Helper waves (hidden sizes up to 512): four extra waves per workgroup, one per SIMD, that never touch the weight
 // stream.  They take everything of a step that is not on the recurrent chain -- gate-gradient slab
 // stores (from the LDS chunk buffers), the stack backward of rows >= 2, dlogits, the DX slab -- and
 // run it under the products of the eight MFMA waves; only rows 0/1 of the stack backward (they need
@@ -182,14 +182,17 @@ __device__ __forceinline__ void gemm_lin(f32x4 (&acc)[NT], const __amdgpu_buffer
 
 // MULTI: more than one GRU layer (only then is the W_ih^T product of a layer carried to the layer
 // below; a single-layer kernel does not hold those accumulators).
-template <int UPW, bool MULTI, bool HELP>
+// NCB: chunk buffers in LDS = chunks (of 128 hidden units) per round of cell backward + products; a
+// divisor of UPW, as large as fits next to the extras tile (a wide vocabulary leaves room for fewer).
+template <int UPW, int NCB, bool MULTI, bool HELP>
 __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS, HELP ? 3 : 2) void pmg_bwd_kernel(const BwdArgs a) {
+  static_assert(UPW % NCB == 0, "chunks per round must divide the chunks of a layer");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int H = a.H, XP = a.XP, W = a.W, D = a.D, V = a.V, L = a.L, B = a.B, G = a.G, N = a.N;
   const int UT = H / 16, NXT = a.NXT;
   const int dbg = PMG_DBG(a.dbg);
-  float* cb = reinterpret_cast<float*>(smem);   // [NCB][16][PMG_CP], NCB = min(H/128, 4)
-  float* dxl = cb + (UPW < 4 ? UPW : 4) * 16 * PMG_CP;            // [16][XP]   dctrl | dpush | dlogits
+  float* cb = reinterpret_cast<float*>(smem);   // [NCB][16][PMG_CP]
+  float* dxl = cb + NCB * 16 * PMG_CP;          // [16][XP]   dctrl | dpush | dlogits
   float* dtl = dxl + 16 * XP;                   // [16][PMG_XTP] dtop
   float* red = dtl + 16 * PMG_XTP;              // [8][4][12]
   float* lsl = red + PMG_WAVES * 48;            // [16] loss terms
@@ -238,7 +241,6 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
   const float rowR = (row0 + (tid & 15) < B) ? a.reward[row0 + (tid & 15)] : 0.0f;  // reward of row tid&15
   __syncthreads();
 
-  constexpr int NCB = UPW < 4 ? UPW : 4;  // chunk buffers (and chunks per round)
 #ifdef PMG_PROFILE
   // -DPMG_PROFILE build + PMG_DEBUG bit 0x8000: per-phase cycle counters of workgroup 0, printed at the end
   const bool prof = (dbg & 0x8000) != 0;
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
       {
         const int dl_row = row0 + hb;
         int y = 0;
-        if (p >= 1 && dl_row < B) y = (int)a.tokens[(size_t)p * B + dl_row];
+        if (p >= 1 && dl_row < B) y = min(max((int)a.tokens[(size_t)p * B + dl_row], 0), V - 1);  // clamped like the forward
         float pr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         const float* prp = a.PR + (((size_t)(p > 0 ? p - 1 : 0) * G + g) * a.VP) * 16 + hb;
 #pragma unroll
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
     int dl_y = 0;
     float dl_pr[2] = {0.0f, 0.0f};
     if (!HELP && p >= 1) {
-      dl_y = (dl_row < B) ? (int)a.tokens[(size_t)p * B + dl_row] : 0;
+      dl_y = (dl_row < B) ? min(max((int)a.tokens[(size_t)p * B + dl_row], 0), V - 1) : 0;  // clamped like the forward
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int v = (tid >> 4) + 32 * k;
@@ -798,29 +800,59 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
 
 }  // namespace
 
-size_t pmg_bwd_lds_bytes(const BwdArgs* a) {
-  const size_t ncb = (a->H / 128 < 4) ? a->H / 128 : 4;
-  return (ncb * 16 * PMG_CP + (size_t)16 * a->XP + 16 * PMG_XTP + PMG_WAVES * 48 + 16) * sizeof(float);
+// Chunk buffers per round: the largest divisor of H/128 that is at most 4 and whose buffers fit the
+// CU's 160 KiB next to the extras tile; 0 if not even one fits.
+static size_t bwd_lds_bytes_ncb(const BwdArgs* a, int ncb) {
+  return ((size_t)ncb * 16 * PMG_CP + (size_t)16 * a->XP + 16 * PMG_XTP + PMG_WAVES * 48 + 16) * sizeof(float);
+}
+int pmg_bwd_chunk_buffers(const BwdArgs* a) {
+  const int upw = a->H / 128;
+  for (int ncb = upw < 4 ? upw : 4; ncb >= 1; --ncb)
+    if (upw % ncb == 0 && bwd_lds_bytes_ncb(a, ncb) <= (size_t)160 * 1024) return ncb;
+  return 0;
 }
 
-template <int UPW, bool MULTI, bool HELP = false>
+size_t pmg_bwd_lds_bytes(const BwdArgs* a) { return bwd_lds_bytes_ncb(a, pmg_bwd_chunk_buffers(a)); }
+
+template <int UPW, int NCB, bool MULTI, bool HELP>
 static hipError_t launch_bwd_t(const BwdArgs* a, hipStream_t st) {
-  const size_t lds = pmg_bwd_lds_bytes(a);
-  auto kern = pmg_bwd_kernel<UPW, MULTI, HELP>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds);
+  const size_t lds = bwd_lds_bytes_ncb(a, NCB);
+  auto kern = pmg_bwd_kernel<UPW, NCB, MULTI, HELP>;
+  static std::atomic<unsigned long long> lds_done{0};
+  hipError_t e = pmg_full_lds_once(reinterpret_cast<const void*>(kern), &lds_done);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(a->G), dim3(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS), lds, st, *a);
   return hipGetLastError();
 }
 
+template <int UPW, int NCB, bool HELP>
+static hipError_t launch_bwd_m(const BwdArgs* a, hipStream_t st) {
+  return a->L > 1 ? launch_bwd_t<UPW, NCB, true, HELP>(a, st) : launch_bwd_t<UPW, NCB, false, HELP>(a, st);
+}
+
+// helper waves up to hidden 512 (168 VGPRs per thread); above, the accumulators need the 8-wave form
+template <int UPW>
+static hipError_t launch_bwd_u(const BwdArgs* a, hipStream_t st) {
+  constexpr bool HELP = (PMG_BWD_HELP != 0) && UPW <= 4;
+  switch (pmg_bwd_chunk_buffers(a)) {
+    case 4: if constexpr (UPW % 4 == 0) return launch_bwd_m<UPW, 4, HELP>(a, st); break;
+    case 3: if constexpr (UPW % 3 == 0) return launch_bwd_m<UPW, 3, HELP>(a, st); break;
+    case 2: if constexpr (UPW % 2 == 0) return launch_bwd_m<UPW, 2, HELP>(a, st); break;
+    case 1: return launch_bwd_m<UPW, 1, HELP>(a, st);
+  }
+  return hipErrorInvalidValue;
+}
+
 hipError_t pmg_launch_bwd(const BwdArgs* a, hipStream_t st) {
-  const bool m = a->L > 1;
   switch (a->H) {
-    case 128: return m ? launch_bwd_t<1, true, PMG_BWD_HELP != 0>(a, st) : launch_bwd_t<1, false, PMG_BWD_HELP != 0>(a, st);
-    case 256: return m ? launch_bwd_t<2, true, PMG_BWD_HELP != 0>(a, st) : launch_bwd_t<2, false, PMG_BWD_HELP != 0>(a, st);
-    case 512: return m ? launch_bwd_t<4, true, PMG_BWD_HELP != 0>(a, st) : launch_bwd_t<4, false, PMG_BWD_HELP != 0>(a, st);
-    case 1024: return m ? launch_bwd_t<8, true>(a, st) : launch_bwd_t<8, false>(a, st);
+    case 128: return launch_bwd_u<1>(a, st);
+    case 256: return launch_bwd_u<2>(a, st);
+    case 384: return launch_bwd_u<3>(a, st);
+    case 512: return launch_bwd_u<4>(a, st);
+    case 640: return launch_bwd_u<5>(a, st);
+    case 768: return launch_bwd_u<6>(a, st);
+    case 896: return launch_bwd_u<7>(a, st);
+    case 1024: return launch_bwd_u<8>(a, st);
   }
   return hipErrorInvalidValue;
 }

@@ -15,6 +15,7 @@
 #define PMG_WAVES 8     // waves per workgroup
 #define PMG_THREADS 512 // PMG_WAVES * 64
 #define PMG_KS 64       // stack width padded to a multiple of 16 (K of the stack-top GEMM)
+#define PMG_MAX_VOCAB 1024
 #define PMG_XTP 72      // LDS pitch of the stack-top tile (64 + 8: conflict-free ds_read_b128)
 #define PMG_CHUNK 128   // hidden units per backward chunk (PMG_WAVES * 16)
 #define PMG_CP 520      // LDS pitch of a backward chunk row (4*128 + 8)

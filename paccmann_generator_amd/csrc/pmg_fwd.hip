@@ -623,13 +623,44 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
           for (int v = l5; v < V; v += 32) m = fmaxf(m, lg[v] / T);
 #pragma unroll
           for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-          // running CDF: slot k holds entries 32k..32k+31, one per lane
-          float cdf[8];
-          float carry = 0.0f;
+          const float u = pmg_uniform(a.seed, (uint64_t)(a.seq_base + row), a.offset + (uint64_t)(i - 1));
+          tok = -1;
+          if (V <= 256) {
+            // running CDF: slot k holds entries 32k..32k+31, one per lane
+            float cdf[8];
+            float carry = 0.0f;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            cdf[k] = 0.0f;
-            if (32 * k < V) {
+            for (int k = 0; k < 8; ++k) {
+              cdf[k] = 0.0f;
+              if (32 * k < V) {
+                const int v = 32 * k + l5;
+                float e = (v < V) ? __expf(lg[v] / T - m) : 0.0f;
+#pragma unroll
+                for (int o = 1; o <= 16; o <<= 1) {
+                  const float t = __shfl_up(e, o, 32);
+                  if (l5 >= o) e += t;
+                }
+                cdf[k] = carry + e;
+                carry = __shfl(cdf[k], 31, 32);
+              }
+            }
+            const float target = u * carry;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              if (32 * k < V) {
+                const int v = 32 * k + l5;
+                const unsigned long long bal = __ballot((v < V) && (target < cdf[k]));
+                const unsigned mk = (unsigned)(bal >> (lane & 32));
+                if (tok < 0 && mk) tok = 32 * k + (__ffs(mk) - 1);
+              }
+            }
+          } else {
+            // larger vocabularies: the same slot-wise CDF, formed twice (first for its total, then
+            // for the search) instead of kept in registers; the values are identical both times
+            const int nslot = (V + 31) >> 5;     // uniform: both rows of a wave run in lockstep
+            float carry = 0.0f;
+#pragma unroll 1
+            for (int k = 0; k < nslot; ++k) {
               const int v = 32 * k + l5;
               float e = (v < V) ? __expf(lg[v] / T - m) : 0.0f;
 #pragma unroll
@@ -637,20 +668,24 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
                 const float t = __shfl_up(e, o, 32);
                 if (l5 >= o) e += t;
               }
-              cdf[k] = carry + e;
-              carry = __shfl(cdf[k], 31, 32);
+              carry = __shfl(carry + e, 31, 32);
             }
-          }
-          const float u = pmg_uniform(a.seed, (uint64_t)(a.seq_base + row), a.offset + (uint64_t)(i - 1));
-          const float target = u * carry;
-          tok = -1;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            if (32 * k < V) {
+            const float target = u * carry;
+            carry = 0.0f;
+#pragma unroll 1
+            for (int k = 0; k < nslot; ++k) {
               const int v = 32 * k + l5;
-              const unsigned long long bal = __ballot((v < V) && (target < cdf[k]));
+              float e = (v < V) ? __expf(lg[v] / T - m) : 0.0f;
+#pragma unroll
+              for (int o = 1; o <= 16; o <<= 1) {
+                const float t = __shfl_up(e, o, 32);
+                if (l5 >= o) e += t;
+              }
+              const float c = carry + e;
+              const unsigned long long bal = __ballot((v < V) && (target < c));
               const unsigned mk = (unsigned)(bal >> (lane & 32));
               if (tok < 0 && mk) tok = 32 * k + (__ffs(mk) - 1);
+              carry = __shfl(c, 31, 32);
             }
           }
           if (tok < 0) tok = V - 1;
@@ -902,8 +937,8 @@ template <int WV, int UPW, int TPP, int MODE, bool MULTI>
 static hipError_t launch_fwd_t(const FwdArgs* a, hipStream_t st) {
   const size_t lds = pmg_fwd_lds_bytes(a);
   auto kern = pmg_fwd_kernel<WV, UPW, TPP, MODE, MULTI>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds);
+  static std::atomic<unsigned long long> lds_done{0};
+  hipError_t e = pmg_full_lds_once(reinterpret_cast<const void*>(kern), &lds_done);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(a->G), dim3(WV * 64), lds, st, *a);
   return hipGetLastError();
@@ -935,6 +970,12 @@ hipError_t pmg_launch_fwd(const FwdArgs* a, hipStream_t st) {
   switch (a->H) {
     case 128: return launch_fwd_h<8, 1, 1>(a, st);
     case 256: return launch_fwd_h<8, 2, 2>(a, st);
+    // hidden sizes between the power-of-two ones (model_params.json is free to name them): the same
+    // kernel with another number of unit tiles per wave
+    case 384: return launch_fwd_h<8, 3, 1>(a, st);
+    case 640: return launch_fwd_h<8, 5, 1>(a, st);
+    case 768: return launch_fwd_h<8, 6, 2>(a, st);
+    case 896: return launch_fwd_h<8, 7, 1>(a, st);
 #if PMG_FWD_WV512 == 16
     case 512: return launch_fwd_h<16, 2, PMG_FWD_TPP16>(a, st);
 #else

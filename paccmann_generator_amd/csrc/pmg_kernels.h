@@ -2,6 +2,21 @@
 // include/pmg.h).
 #pragma once
 #include "pmg_common.h"
+#include <atomic>
+
+// hipFuncAttributeMaxDynamicSharedMemorySize raised to the CU's whole 160 KiB ONCE per kernel
+// instance and device (`done`: one bit per device, a static of the launcher's instantiation), not per
+// launch: a launch path without the call is cheaper and safe under HIP graph capture.
+static inline hipError_t pmg_full_lds_once(const void* kern, std::atomic<unsigned long long>* done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done->load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) done->fetch_or(bit, std::memory_order_release);
+  return e;
+}
 
 // ------------------------------------------------------------------ packing
 enum PackKind {
@@ -107,3 +122,4 @@ struct BwdArgs {
 
 hipError_t pmg_launch_bwd(const BwdArgs* a, hipStream_t st);
 size_t pmg_bwd_lds_bytes(const BwdArgs* a);
+int pmg_bwd_chunk_buffers(const BwdArgs* a);

@@ -223,14 +223,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void pmg_wgrad_kernel(const WgradArg
 }
 
 // tok32[p][g][r] = token fed at step p to row 16g+r (int32), -1 for rows past the batch.
-__global__ void pmg_tok32_kernel(const int64_t* __restrict__ tokens, int B, int G, int N, int32_t* __restrict__ out) {
+__global__ void pmg_tok32_kernel(const int64_t* __restrict__ tokens, int B, int G, int N, int V, int32_t* __restrict__ out) {
   const size_t total = (size_t)N * G * 16;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(idx & 15);
     const size_t sl = idx >> 4;
     const int p = (int)(sl / G), g = (int)(sl - (size_t)p * G);
     const int row = g * 16 + r;
-    out[idx] = row < B ? (int32_t)tokens[(size_t)p * B + row] : -1;
+    out[idx] = row < B ? (int32_t)min(max(tokens[(size_t)p * B + row], (int64_t)0), (int64_t)(V - 1)) : -1;  // clamped like the forward
   }
 }
 
@@ -512,7 +512,7 @@ hipError_t pmg_run_wgrad(const PmgDims& d, const PmgLayout& lay, float* ws, cons
     const size_t total = (size_t)(d.T - 1) * d.G * 16;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(pmg_tok32_kernel, dim3(blocks), dim3(256), 0, st, tokens, d.B, d.G, d.T - 1, tok32);
+    hipLaunchKernelGGL(pmg_tok32_kernel, dim3(blocks), dim3(256), 0, st, tokens, d.B, d.G, d.T - 1, d.V, tok32);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

@@ -21,7 +21,7 @@ def test_header_declares_the_expected_entry_points():
     assert declared_functions() == sorted([
         'pmg_abi_version', 'pmg_strerror', 'pmg_check_shape', 'pmg_workspace_bytes', 'pmg_decode',
         'pmg_logprob_fwd', 'pmg_reinforce_bwd', 'pmg_step', 'pmg_detokenize', 'pmg_decode_noalloc',
-        'pmg_noalloc_scratch_bytes'])
+        'pmg_noalloc_scratch_bytes', 'pmg_reinforce_bptt', 'pmg_reinforce_wgrad'])
 
 
 def test_library_exports_every_declared_symbol():
@@ -63,7 +63,7 @@ def test_shape_checks_and_error_text():
     bad = [
         _ffi.make_shape(8, 4, 100, 16, 10, 7, 23, 1, 32, 0),     # H not supported
         _ffi.make_shape(8, 4, 128, 16, 65, 7, 23, 1, 32, 0),     # W > 64
-        _ffi.make_shape(8, 4, 128, 16, 10, 7, 250, 1, 32, 0),    # 3+W+V > 256
+        _ffi.make_shape(8, 4, 128, 16, 10, 7, 1025, 1, 32, 0),   # V > 1024
         _ffi.make_shape(8, 4, 128, 16, 10, 7, 23, 5, 32, 0),     # L > 4
         _ffi.make_shape(0, 4, 128, 16, 10, 7, 23, 1, 32, 0),     # empty batch
         _ffi.make_shape(8, 1, 128, 16, 10, 7, 23, 1, 32, 0),     # train needs T >= 2
@@ -78,6 +78,17 @@ def test_shape_checks_and_error_text():
             _ffi.workspace_bytes(s, _ffi.PMG_MODE_TRAIN)
     assert len(codes) >= 5
     assert _ffi.lib.pmg_check_shape(None, 0) < 0
+    # the envelope of StackGRUDecoder(params) (train_paccmann_rl.py:93-97): every multiple of 128 up to
+    # 1024 as hidden size, vocabularies of a few hundred tokens
+    for H in range(128, 1025, 128):
+        for V in (23, 60, 300, 575, 1024):
+            s = _ffi.make_shape(64, 102, H, 128, 50, 50, V, 1, 256, 0)
+            assert _ffi.lib.pmg_check_shape(C.byref(s), _ffi.PMG_MODE_TRAIN) == 0, (H, V)
+            assert _ffi.lib.pmg_check_shape(C.byref(s), _ffi.PMG_MODE_DECODE) == 0, (H, V)
+    # ... up to what one CU's LDS can hold: 4 layers of hidden 1024 next to a 1024-token vocabulary cannot
+    s = _ffi.make_shape(64, 102, 1024, 128, 50, 50, 1024, 4, 256, 0)
+    rc = _ffi.lib.pmg_check_shape(C.byref(s), _ffi.PMG_MODE_TRAIN)
+    assert rc < 0 and b'LDS' in _ffi.lib.pmg_strerror(rc)
 
 
 def test_workspace_size_scales_with_batch_and_time():

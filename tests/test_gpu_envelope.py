@@ -1,0 +1,73 @@
+"""The shape envelope of StackGRUDecoder(params): the reference builds its decoder from an arbitrary
+model_params.json (examples/IC50/train_paccmann_rl.py:93-97), so hidden sizes between the
+power-of-two ones and SELFIES alphabets of a few hundred tokens have to work -- to the same bar as
+the BASELINE configurations: greedy tokens exact, sampled tokens = the oracle's inverse-CDF choice for
+the same Philox uniform, log-probs and every gradient within 1e-4 of the fp64 oracle."""
+import pytest
+import torch
+
+from tests import parity as P
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+MID = dict(embedding_size=32, stack_width=20, stack_depth=12, n_layers=1, latent_dim=64, pad_index=0, vocab_size=40)
+
+
+@pytest.mark.parametrize('H', [384, 640, 768, 896])
+def test_hidden_sizes_between_the_powers_of_two(gpu, H):
+    cfg = dict(MID, rnn_cell_size=H)
+    P.check_train(cfg, B=19, T=11, tol=TOL)
+    assert P.check_greedy(cfg, 21, 14)['mismatched_rows'] == 0
+    P.check_step(cfg, 18)
+
+
+@pytest.mark.parametrize('H', [384, 768])
+def test_hidden_384_768_two_layers_and_reference_stack(gpu, H):
+    cfg = dict(P.CFG1, rnn_cell_size=H, n_layers=2)      # E=128, stack 50x50, V=60 as the BASELINE configs
+    P.check_train(cfg, B=18, T=30, tol=TOL)
+    r = P.check_greedy(cfg, 20, 40)
+    assert r['mismatched_rows'] == r['near_ties']
+
+
+@pytest.mark.parametrize('V', [300, 575])
+@pytest.mark.parametrize('H', [128, 512])
+def test_vocabularies_of_a_few_hundred_tokens(gpu, V, H):
+    cfg = dict(MID, rnn_cell_size=H, vocab_size=V)
+    P.check_train(cfg, B=21, T=9, tol=TOL)
+    assert P.check_greedy(cfg, 19, 12)['mismatched_rows'] == 0
+    r = P.check_sampling(cfg, 18, 10, temperature=1.2)      # V > 256: the two-pass CDF of the sampler
+    assert r['exact'] + r['boundary'] == 18 * 10 and r['boundary'] <= 2
+    P.check_step(cfg, 17)
+
+
+def test_wide_vocabulary_with_the_reference_stack_and_hidden_768(gpu):
+    cfg = dict(P.CFG1, rnn_cell_size=768, vocab_size=575)
+    P.check_train(cfg, B=17, T=20, tol=TOL)
+    assert P.check_greedy(cfg, 18, 24)['mismatched_rows'] == 0
+
+
+def test_out_of_range_token_ids_are_clamped_consistently(gpu):
+    """ids outside [0, V) are rejected on the host by ops.reinforce_loss; a caller that skips that check
+    (trusted_tokens=True) gets them clamped the same way by the forward, the BPTT and the
+    weight-gradient kernels, i.e. exactly the result of the clamped ids."""
+    from paccmann_generator_amd import _ffi, ops
+    _, pdec = P.make_pair(dict(P.TINY, vocab_size=97), seed=0)       # V > 64: the one-hot job reads the ids too
+    tokens = P.synthetic_tokens(8, 20, 97, seed=4).cuda()
+    bad = tokens.clone()
+    bad[2, 3], bad[4, 7], bad[5, 0] = 97, 4000, -5
+    torch.manual_seed(1)
+    h0 = torch.tanh(torch.randn(1, 20, 128)).cuda()
+    reward = torch.rand(20).cuda()
+    with pytest.raises(_ffi.PmgError):
+        ops.reinforce_loss(pdec.weights(), bad, h0, reward, 0.05)
+    outs = []
+    for t in (bad, bad.clamp(0, 96)):
+        for p in pdec.parameters():
+            p.grad = None
+        h = h0.clone().requires_grad_(True)
+        loss, logp = ops.reinforce_loss(pdec.weights(), t, h, reward, 0.05, trusted_tokens=True)
+        loss.backward()
+        outs.append((loss.item(), logp.clone(), h.grad.clone(), [p.grad.clone() for p in pdec.parameters() if p.grad is not None]))
+    (l0, lp0, g0, ps0), (l1, lp1, g1, ps1) = outs
+    assert l0 == l1 and torch.equal(lp0, lp1) and torch.equal(g0, g1)
+    assert all(torch.equal(a, b) for a, b in zip(ps0, ps1))

@@ -32,8 +32,10 @@ st = _ffi.current_stream()
 
 def fwd():
     _ffi.check(_ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(h0), _ffi._ptr(logp), None, 0, _ffi._ptr(ws), st), 'fwd')
-def bwd(flags):
-    _ffi.check(_ffi.lib.pmg_reinforce_bwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(rewards), 1.0 / B, flags, C.byref(gstruct), _ffi._ptr(gh0), _ffi._ptr(loss), _ffi._ptr(ws), st), 'bwd')
+def bptt():
+    _ffi.check(_ffi.lib.pmg_reinforce_bptt(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(rewards), 1.0 / B, _ffi._ptr(gh0), _ffi._ptr(ws), st), 'bptt')
+def wgrad():
+    _ffi.check(_ffi.lib.pmg_reinforce_wgrad(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), 0, C.byref(gstruct), _ffi._ptr(loss), _ffi._ptr(ws), st), 'wgrad')
 def timed(fn, reps=3):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -53,6 +55,6 @@ fwd()
 for bits, nm in names.items():
     if bits & 0x2000 and bits != (0x1F00 | 0x2000) and bits != (0x100 | 0x1000 | 0x2000): continue
     os.environ['PMG_DEBUG'] = hex(bits)
-    print(f'bptt {nm:28s} {timed(lambda: bwd(_ffi.PMG_FLAG_SKIP_WGRAD)):8.3f} ms', flush=True)
+    print(f'bptt {nm:28s} {timed(bptt):8.3f} ms', flush=True)
 os.environ['PMG_DEBUG'] = '0'
-print(f'wgrad {timed(lambda: bwd(_ffi.PMG_FLAG_ONLY_WGRAD)):8.3f} ms')
+print(f'wgrad {timed(wgrad):8.3f} ms')

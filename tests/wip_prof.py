@@ -33,12 +33,14 @@ loss = torch.empty(1, device=dev)
 st = _ffi.current_stream()
 def fwd():
     _ffi.check(_ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(h0), _ffi._ptr(logp), None, 0, _ffi._ptr(ws), st), 'fwd')
-def bwd(flags):
-    _ffi.check(_ffi.lib.pmg_reinforce_bwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(rewards), 1.0 / B, flags, C.byref(gstruct), _ffi._ptr(gh0), _ffi._ptr(loss), _ffi._ptr(ws), st), 'bwd')
-fwd(); bwd(_ffi.PMG_FLAG_SKIP_WGRAD); torch.cuda.synchronize()
+def bptt():
+    _ffi.check(_ffi.lib.pmg_reinforce_bptt(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(rewards), 1.0 / B, _ffi._ptr(gh0), _ffi._ptr(ws), st), 'bptt')
+def wgrad():
+    _ffi.check(_ffi.lib.pmg_reinforce_wgrad(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), 0, C.byref(gstruct), _ffi._ptr(loss), _ffi._ptr(ws), st), 'wgrad')
+fwd(); bptt(); torch.cuda.synchronize()
 os.environ['PMG_DEBUG'] = hex(0x8000 | int(os.environ.get('ABL', '0'), 16))
 for which in os.environ.get('WHICH', 'fwd,bwd').split(','):
     if which == 'fwd': fwd()
     elif which == 'dec': ops.decode(w, latent, 2, 3, T, temperature=0.8, seed=1, early_exit=False)
-    else: bwd(_ffi.PMG_FLAG_SKIP_WGRAD)
+    else: bptt()
     torch.cuda.synchronize()
