@@ -136,14 +136,29 @@ def presampled_tokens(n, T, V, device, seed=5):
     return toks.to(device)
 
 
+def kernel_source_hash():
+    """sha256 over the HIP sources and headers the library is built from."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, 'paccmann_generator_amd', 'csrc')
+    for path in sorted(os.path.join(csrc, f) for f in os.listdir(csrc)) + [os.path.join(ROOT, 'include', 'pmg.h')]:
+        with open(path, 'rb') as f:
+            h.update(os.path.basename(path).encode() + b'\0' + f.read())
+    return h.hexdigest()
+
+
 def pmc_traffic(config, B, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/pmc_traffic.json, made by profiles/summarize_pmc.py); None when the committed
-    passes were taken at another configuration."""
+    (profiles/pmc_traffic[_<config>].json, made by profiles/summarize_pmc.py; the counters cannot be
+    read from inside a timed run).  None when the committed passes were taken at another configuration
+    or batch, or on kernel sources other than the ones in the tree now (stale)."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+        name = 'pmc_traffic.json' if config == 'cfg2' else f'pmc_traffic_{config}.json'
+        with open(os.path.join(ROOT, 'profiles', name)) as f:
             t = json.load(f)
         if t.get('config') != config or t.get('batch') != B:
+            return None
+        if t.get('kernel_sources_sha256') != kernel_source_hash():
             return None
         return t['kernels'][kernel]['total_GB'] * 1e9
     except (OSError, KeyError, ValueError):

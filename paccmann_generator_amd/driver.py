@@ -21,8 +21,11 @@ affinity   protein, SMILES, Binding     pred > 0.5                         every
 =========  ===========================  =================================  ==========================
 
 The toxicity column is filled by ``tox_fn(smiles) -> float`` when given (the reference calls the
-Tox21 evaluator, out of scope here: SURVEY.md section 2 row 6) and is left out otherwise.  Out of
-scope as well: the baseline comparison plots, ratios.csv and the argparse/JSON handling.
+Tox21 evaluator, out of scope here: SURVEY.md section 2 row 6) and is left out otherwise.  The
+'affinity' preset also writes ``results/ratios.csv`` at the end (train_conditional_generator.py:283-289,
+317-320): per epoch the percentage of ALL evaluated molecules with pred > 0.5 (``efficacy_ratio``) and,
+with ``tox_fn``, of those with tox_fn == 1 (``tox_ratio``), both rounded to one decimal.  Out of scope:
+the baseline comparison plots and the argparse/JSON handling.
 """
 from __future__ import annotations
 
@@ -65,6 +68,7 @@ def train(learner, train_targets: Sequence, test_targets: Sequence, params: dict
     pool = [t for t in train_targets if t != held_out] if held_out is not None else list(train_targets)
     columns = [ps['target_col'], 'SMILES', ps['pred_col'], 'mode'] + ([ps['tox_col']] if tox_fn is not None else [])
     target = None
+    biased_ratios, tox_ratios = [], []
     for epoch in range(1, params['epochs'] + 1):
         for step in range(1, params['steps']):
             target = pool[rng.randint(len(pool))]
@@ -84,6 +88,13 @@ def train(learner, train_targets: Sequence, test_targets: Sequence, params: dict
             if tgt is None:
                 continue
             smiles, preds = learner.generate_compounds_and_evaluate(epoch, params.get('eval_batch_size', 32), tgt)
+            if preset == 'affinity':     # train_conditional_generator.py:283-289 (nan for an empty evaluation, as there)
+                pa = np.atleast_1d(np.asarray(preds, dtype=np.float64))
+                with np.errstate(invalid='ignore', divide='ignore'):
+                    biased_ratios.append(np.round(100 * (np.sum(pa > 0.5) / np.float64(len(pa))), 1))
+                    if tox_fn is not None:
+                        toxes = np.array([tox_fn(s) for s in smiles])
+                        tox_ratios.append(np.round(100 * (np.sum(toxes == 1.) / np.float64(len(toxes))), 1))
             for s, p in zip(smiles, np.atleast_1d(preds)):
                 if keep(p):
                     row = {ps['target_col']: tgt, 'SMILES': s, ps['pred_col']: float(p), 'mode': mode}
@@ -93,4 +104,9 @@ def train(learner, train_targets: Sequence, test_targets: Sequence, params: dict
         pd.DataFrame(rows, columns=columns).to_csv(os.path.join(results, 'generated.csv'))
         pd.DataFrame({'loss': rl_losses, 'rewards': rewards}).to_csv(
             os.path.join(results, 'loss_reward_evolution.csv'))
+    if preset == 'affinity':             # train_conditional_generator.py:317-320
+        cols = {'efficacy_ratio': biased_ratios}
+        if tox_fn is not None:
+            cols['tox_ratio'] = tox_ratios
+        pd.DataFrame(cols).to_csv(os.path.join(results, 'ratios.csv'))
     return rewards, rl_losses, rows

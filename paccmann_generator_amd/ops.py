@@ -29,9 +29,23 @@ from torch import Tensor
 from . import _ffi
 
 # Largest workspace one kernel call of the training pair may take; larger batches run as chunks whose
-# gradients accumulate (PMG_FLAG_ACCUMULATE).  96 GiB of the 288 GB of HBM: configs[3] (2 layers,
-# hidden 1024, T=258) needs ~20 GB per 1024 sequences, so B=16384 runs as 4 chunks of 4096.
+# gradients accumulate (PMG_FLAG_ACCUMULATE).  At most 96 GiB of the 288 GB of HBM -- configs[3]
+# (2 layers, hidden 1024, T=258) needs ~20 GB per 1024 sequences, so B=16384 runs as 4 chunks of 4096 --
+# and at most WORKSPACE_FREE_FRACTION of what is free on the device at call time (workspace_budget),
+# so that a co-tenant, a second rank on the same GPU or a caller's large resident tensors get smaller
+# chunks instead of an out-of-memory error.
 WORKSPACE_BUDGET_BYTES = 96 << 30
+WORKSPACE_FREE_FRACTION = 0.9
+
+
+def workspace_budget(device=None) -> int:
+    """min(WORKSPACE_BUDGET_BYTES, WORKSPACE_FREE_FRACTION x free bytes), free = what the driver
+    reports (hipMemGetInfo) plus the blocks torch's caching allocator holds but has not handed out."""
+    if not (torch.cuda.is_available() and torch.cuda.is_initialized()):
+        return WORKSPACE_BUDGET_BYTES
+    free, _ = torch.cuda.mem_get_info(device)
+    cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+    return int(min(WORKSPACE_BUDGET_BYTES, WORKSPACE_FREE_FRACTION * (free + cached)))
 
 
 def release_workspaces() -> None:
@@ -303,19 +317,25 @@ def _(tokens, reward, scale, ws, params, stack_depth, pad_idx):
             [torch.empty_like(p) for p in params])
 
 
-def plan_chunks(d: dict, B: int, T: int, budget: Optional[int] = None, chunk: int = 0) -> List[Tuple[int, int]]:
+def plan_chunks(d: dict, B: int, T: int, budget: Optional[int] = None, chunk: int = 0,
+                device=None) -> List[Tuple[int, int]]:
     """[lo, hi) slices of the batch, each a whole number of 16-sequence row groups (but the last),
-    whose training workspace fits ``budget`` bytes.  ``chunk`` > 0 fixes the slice size instead."""
+    whose training workspace fits ``budget`` bytes (default: workspace_budget(device), derived from
+    the memory free on the device right now).  ``chunk`` > 0 fixes the slice size instead."""
     if chunk <= 0:
-        budget = WORKSPACE_BUDGET_BYTES if budget is None else int(budget)
-        per16 = _ffi.workspace_bytes(_shape(d, 32, T), _ffi.PMG_MODE_TRAIN) - \
-            _ffi.workspace_bytes(_shape(d, 16, T), _ffi.PMG_MODE_TRAIN)
-        fixed = _ffi.workspace_bytes(_shape(d, 16, T), _ffi.PMG_MODE_TRAIN) - per16
+        budget = workspace_budget(device) if budget is None else int(budget)
+        need = lambda n: _ffi.workspace_bytes(_shape(d, n, T), _ffi.PMG_MODE_TRAIN)      # noqa: E731
+        per16 = need(32) - need(16)
+        fixed = need(16) - per16
         groups = max(1, int((budget - fixed) // max(1, per16)))
-        chunk = groups * 16
+        chunk = min(groups * 16, -(-B // 16) * 16)
         if chunk < B:    # balance: same number of chunks, equal sizes
             n = -(-B // chunk)
             chunk = -(-(-(-B // n)) // 16) * 16
+        # the estimate is linear in the row groups; the split-K partial buffers of the weight-gradient
+        # GEMM need not be: check the real size and give row groups back until it fits
+        while chunk > 16 and need(min(chunk, B)) > budget:
+            chunk -= 16
     else:
         chunk = -(-int(chunk) // 16) * 16
     return [(lo, min(B, lo + chunk)) for lo in range(0, B, chunk)]
@@ -340,7 +360,7 @@ def _reinforce_loss_op(tokens: Tensor, h0: Tensor, reward: Tensor, scale: float,
     if reward.numel() != B:
         raise _ffi.PmgError('pmg: one reward per sequence required')
     L, H = d['L'], d['H']
-    chunks = plan_chunks(d, B, T, chunk=chunk)
+    chunks = plan_chunks(d, B, T, chunk=chunk, device=dev)
     wstruct, keep = _wstruct(params, L)
     logp = torch.empty(T - 1, B, dtype=torch.float32, device=dev)
     if with_grads:

@@ -2,7 +2,7 @@
 """MFMA utilisation per kernel from the `mfma` pass of profiles/profile_all.sh
 (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE).
 
-usage: python profiles/summarize_mfma.py gpurun_out/prof6 r01"""
+usage: python profiles/summarize_mfma.py gpurun_out/prof6 r01 [--label 'cfg4 B=4096']"""
 import collections
 import csv
 import os
@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def main():
     d, tag = sys.argv[1], sys.argv[2]
+    label = sys.argv[sys.argv.index('--label') + 1] if '--label' in sys.argv else 'cfg2 B=4096'
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(os.path.join(d, 'mfma_counter_collection.csv'))):
         k = r['Kernel_Name']
@@ -21,7 +22,7 @@ def main():
             agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
     med = statistics.median
     lines = [f'# {tag} MFMA counters per launch (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES '
-             'SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE), cfg2 B=4096', '',
+             f'SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE), {label}', '',
              'MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8 XCDs) * 1024 SIMDs): GRBM_GUI_ACTIVE comes back '
              'summed over the 8 XCDs, the busy counter summed over all SIMDs.',
              'MFMA flop = SQ_INSTS_VALU_MFMA_MOPS_F32 * 512.  pmg_fwd_kernel<WV, UPW, TPP, MODE, MULTI>: MODE 0 = decode, '

@@ -16,6 +16,7 @@ import statistics
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
 
 
 def main():
@@ -68,13 +69,17 @@ def main():
              'FETCH_SIZE doubled (gfx950 correction for 16 B/lane reads), WRITE_SIZE as is; GB = 1e9 B; medians '
              'over the launches of the run.', '',
              '| kernel | launches | FETCH_SIZE raw GB | read GB (x2) | written GB | total GB |', '|---|---|---|---|---|---|']
-    js = {'config': config, 'batch': batch, 'tag': tag, 'kernels': {}}
+    from bench import kernel_source_hash
+    # the hash ties the figures to the kernel sources they were measured on: bench.py reports
+    # roofline.traffic only while the sources are unchanged
+    js = {'config': config, 'batch': batch, 'tag': tag, 'kernel_sources_sha256': kernel_source_hash(), 'kernels': {}}
     for key, short, n, f, w in rows:
         lines.append(f'| {short} | {n or ""} | {f:.2f} | {2 * f:.2f} | {w:.2f} | {2 * f + w:.2f} |')
         if key:
             js['kernels'][key] = {'read_GB': round(2 * f, 3), 'write_GB': round(w, 3), 'total_GB': round(2 * f + w, 3)}
     open(os.path.join(HERE, f'{tag}_pmc_hbm.md'), 'w').write('\n'.join(lines) + '\n')
-    json.dump(js, open(os.path.join(HERE, 'pmc_traffic.json'), 'w'), indent=1)
+    out_json = 'pmc_traffic.json' if config == 'cfg2' else f'pmc_traffic_{config}.json'
+    json.dump(js, open(os.path.join(HERE, out_json), 'w'), indent=1)
     print('\n'.join(lines))
 
 

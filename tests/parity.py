@@ -102,14 +102,18 @@ def product_train(pdec, tokens, h0, reward, scale, chunk=0):
     return loss.item(), logp.cpu(), grads, h0d.grad.detach().cpu().clone()
 
 
-def check_train(params, B, T, seed=0, tol=1e-4, verbose=False, chunk=0, elem_tol=1e-4):
+def check_train(params, B, T, seed=0, tol=1e-4, verbose=False, chunk=0, elem_tol=1e-4, allow_noise=None):
     """Teacher-forced log-probs + REINFORCE gradients, HIP vs oracle autograd in fp64.
 
     Two bars per tensor: max-norm (max|a-b| / max|b| <= tol) and element-wise (elem_err <= elem_tol).
     An element that misses the element-wise bar is accepted only if the fp32 CPU oracle -- the same
     arithmetic in the same precision, another summation order -- is itself at least a third as far
     from the fp64 oracle there: then the miss is fp32 summation noise on a small entry, not a defect.
-    Such entries are listed in report['noise']."""
+    Such entries are listed in report['noise'].  At the BASELINE configurations (CFG1 / CFG2 / CFG4
+    model shapes) no such exception is accepted: there the element-wise bar holds outright (it did in
+    every recorded run), and a miss fails the test.  ``allow_noise`` overrides that default."""
+    if allow_noise is None:
+        allow_noise = not any(all(params.get(k) == c[k] for k in c) for c in (CFG1, CFG2, CFG4))
     odec, pdec = make_pair(params, seed=seed)
     L, H = params['n_layers'], params['rnn_cell_size']
     tokens = synthetic_tokens(T, B, params['vocab_size'], seed=seed + 3)
@@ -153,6 +157,8 @@ def check_train(params, B, T, seed=0, tol=1e-4, verbose=False, chunk=0, elem_tol
             noise[k] = dict(worst=float(e_hip.max()), n=int(over.sum()), fp32_oracle_worst=float(e_f32.max()))
     report['elem'] = {k: v[0] for k, v in elem.items()}
     report['noise'] = noise
+    assert allow_noise or not noise, f'element-wise bar missed at a BASELINE configuration (fp32 noise or not): {noise}'
+
     # parameters the loss cannot reach must stay without gradient
     assert all(not n.startswith('latent_to_hidden') for n in p_grads), p_grads.keys()
     return report

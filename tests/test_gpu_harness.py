@@ -243,3 +243,10 @@ def test_affinity_driver_preset_and_protein_embedding_columns(gpu, tmp_path):
     assert list(gen_csv.columns[1:]) == ['protein', 'SMILES', 'Binding probability', 'mode', 'Tox21']
     assert set(gen_csv['mode']) <= {'eval'} and set(gen_csv['protein']) <= {'p2'}
     assert (gen_csv['Binding probability'] > 0.5).all()
+    # ratios.csv (train_conditional_generator.py:283-289,317-320): one row per epoch, percentages of ALL
+    # evaluated molecules, one decimal
+    ratios = pd.read_csv(os.path.join(learner.model_path, 'results', 'ratios.csv'))
+    assert list(ratios.columns[1:]) == ['efficacy_ratio', 'tox_ratio'] and len(ratios) == 10
+    assert ((ratios['tox_ratio'] == 100.0) | ratios['tox_ratio'].isna()).all()
+    eff = ratios['efficacy_ratio'].dropna()
+    assert ((eff >= 0) & (eff <= 100)).all() and np.allclose(eff * 10, np.round(eff * 10))

@@ -76,3 +76,23 @@ def test_chunk_plan_covers_the_batch_in_row_group_multiples():
     d2 = _decoder(P.CFG2).weights().dims
     assert ops.plan_chunks(d2, 4096, 130) == [(0, 4096)]                     # configs[1]: one call
     assert ops.plan_chunks(d2, 100, 130, chunk=40) == [(0, 48), (48, 96), (96, 100)]
+    # a smaller budget (less memory free on the device: a co-tenant, a second rank on the GPU) gives more,
+    # smaller chunks, each of which really fits -- checked against the library's own size, not the estimate
+    for budget in (6 << 30, 3 << 30, 1 << 30):
+        plan = ops.plan_chunks(d2, 4096, 130, budget=budget)
+        assert plan[0][0] == 0 and plan[-1][1] == 4096 and len(plan) >= 3
+        for lo, hi in plan:
+            assert _ffi.workspace_bytes(ops._shape(d2, hi - lo, 130), _ffi.PMG_MODE_TRAIN) <= budget
+    assert ops.workspace_budget() <= ops.WORKSPACE_BUDGET_BYTES
+
+
+def test_workspace_budget_follows_free_device_memory(monkeypatch):
+    from paccmann_generator_amd import ops
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'is_initialized', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'mem_get_info', lambda device=None: (10 << 30, 288 << 30))
+    monkeypatch.setattr(torch.cuda, 'memory_reserved', lambda device=None: 6 << 30)
+    monkeypatch.setattr(torch.cuda, 'memory_allocated', lambda device=None: 2 << 30)
+    assert ops.workspace_budget() == int(0.9 * (14 << 30))          # free + cached-but-unused
+    monkeypatch.setattr(torch.cuda, 'mem_get_info', lambda device=None: (280 << 30, 288 << 30))
+    assert ops.workspace_budget() == ops.WORKSPACE_BUDGET_BYTES     # capped
