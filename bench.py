@@ -214,7 +214,7 @@ def time_phases(learner, cfg, latent, rewards, B, reps=3):
 
     def f_fwd():
         _ffi.check(_ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(h0),
-                                            _ffi._ptr(logp), None, 0, _ffi._ptr(ws), st), 'fwd')
+                                            _ffi._ptr(logp), None, ops._cluster_flag(), _ffi._ptr(ws), st), 'fwd')
 
     def f_bptt():
         _ffi.check(_ffi.lib.pmg_reinforce_bptt(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(rewards),
@@ -232,6 +232,13 @@ def time_phases(learner, cfg, latent, rewards, B, reps=3):
     return out
 
 
+def _uses_cluster(learner, B, T):
+    import ctypes as C
+    from paccmann_generator_amd import _ffi, ops
+    shape = learner.generator.decoder.weights().shape(B, T)
+    return _ffi.lib.pmg_uses_cluster(C.byref(shape), _ffi.PMG_MODE_DECODE, ops._cluster_flag()) == 1
+
+
 def rank_command(n_gpus: int, argv, port: int):
     """Command line that starts the N ranks of `bench.py --gpus N` (one process per GPU on one node)."""
     return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_gpus}',
@@ -247,6 +254,8 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-phases', action='store_true')
+    ap.add_argument('--no-cluster', action='store_true',
+                    help='small batches: force the batch-partitioned forward kernels (A/B against the clustered ones)')
     ap.add_argument('--seqs', type=int, default=65536, help='cfg5: pre-sampled sequences per step (1M = 1048576)')
     ap.add_argument('--allow-variant', action='store_true',
                     help='permit a tuning build selected by PMG_LIB (ablation / profile variants give wrong or '
@@ -290,6 +299,9 @@ def main():
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
 
+    if args.no_cluster:
+        from paccmann_generator_amd import ops as _ops
+        _ops.USE_CLUSTER = False
     cfg = dict(CONFIGS[args.config])
     B = args.batch or cfg['batch']
     T = cfg['length']
@@ -384,6 +396,7 @@ def main():
         'tokens_per_step_per_gpu': tokens_per_step,
         'replicas_identical': replicas_identical,     # N>1: checked over all ranks after the timed steps
         'dist_backend': (dist.get_backend(pg) if pg is not None else None),
+        'forward_kernels': 'clustered' if _uses_cluster(learner, B, T) else 'batch-partitioned',
     }
     if rank == 0:
         if not args.no_phases:

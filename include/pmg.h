@@ -39,6 +39,10 @@ extern "C" {
                                      pmg_logprob_fwd call on it (same weights, same model dimensions; B and T
                                      may differ): skip the packing kernels.  For batches run in chunks. */
 
+#define PMG_FLAG_NO_CLUSTER 32u   /* decode / logprob_fwd: never take the clustered small-batch kernels (see below).
+                                     Pass it on launches that may run CONCURRENTLY with another pmg_decode /
+                                     pmg_logprob_fwd on the same GPU (other streams or processes). */
+
 typedef void* pmg_stream; /* hipStream_t */
 
 /* Problem shape.  B = sequences in this call, T = time steps:
@@ -95,6 +99,15 @@ const char* pmg_strerror(int code);
  * layers may not) -- else the error code every entry point would return for it. */
 int pmg_check_shape(const pmg_shape* s, int mode);
 
+/* 1 if pmg_decode (mode PMG_MODE_DECODE) / pmg_logprob_fwd (PMG_MODE_TRAIN) would take the
+ * clustered small-batch kernels for shape `s` with these flags, 0 if the batch-partitioned ones,
+ * negative for an unsupported shape.  Clustered: one layer, H <= 512, B <= 16 * 8 * floor(512 / H)
+ * sequences, 3+W+V <= 256; a cluster of H/16 workgroups (one per CU) serves 16 sequences and
+ * synchronises through device memory twice per time step, so every cluster member must be resident
+ * at once: see PMG_FLAG_NO_CLUSTER.  Same results either way (to the tolerances of the parity
+ * tests; greedy tokens exact). */
+int pmg_uses_cluster(const pmg_shape* s, int mode, uint32_t flags);
+
 /* Bytes of device scratch needed for `mode` at shape `s` (256-byte aligned base). */
 int pmg_workspace_bytes(const pmg_shape* s, int mode, size_t* out);
 
@@ -111,7 +124,11 @@ int pmg_workspace_bytes(const pmg_shape* s, int mode, size_t* out);
  *   len_out    [B] tokens before the first stop_tok (gen_len if none): the crop
  *              TeacherVAE.generate applies (consumed at reinforce.py:172-187)
  * A workgroup stops early once all of its rows have emitted stop_tok (remaining
- * positions are filled with stop_tok) unless PMG_FLAG_NO_EARLY_EXIT is set. */
+ * positions are filled with stop_tok) unless PMG_FLAG_NO_EARLY_EXIT is set.
+ * Small batches (pmg_uses_cluster) run on clusters of workgroups with bounded spin barriers: if the
+ * members of a cluster cannot all become resident (another spinning kernel holds the CUs for about a
+ * second) the launch gives up and POISONS its outputs -- len_out = -1 for every row here, NaN in
+ * logp_out of pmg_logprob_fwd -- instead of hanging or returning plausible numbers. */
 int pmg_decode(const pmg_shape* s, const pmg_weights* w, const float* latent,
                int start_tok, int stop_tok, int gen_len, float temperature,
                uint64_t philox_seed, uint64_t philox_offset, int64_t seq_index_base,

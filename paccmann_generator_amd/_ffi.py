@@ -17,6 +17,7 @@ PMG_MODE_TRAIN = 1
 PMG_FLAG_NO_EARLY_EXIT = 1
 PMG_FLAG_ACCUMULATE = 2
 PMG_FLAG_REUSE_PACK = 16
+PMG_FLAG_NO_CLUSTER = 32
 PMG_ABI_VERSION = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -54,7 +55,7 @@ class PmgGrads(C.Structure):
 EXPORTS = (
     'pmg_abi_version', 'pmg_strerror', 'pmg_check_shape', 'pmg_workspace_bytes',
     'pmg_decode', 'pmg_logprob_fwd', 'pmg_reinforce_bwd', 'pmg_step', 'pmg_detokenize',
-    'pmg_decode_noalloc', 'pmg_noalloc_scratch_bytes', 'pmg_reinforce_bptt', 'pmg_reinforce_wgrad',
+    'pmg_decode_noalloc', 'pmg_noalloc_scratch_bytes', 'pmg_reinforce_bptt', 'pmg_reinforce_wgrad', 'pmg_uses_cluster',
 )
 
 
@@ -71,6 +72,7 @@ def _load():
     lib.pmg_strerror.restype = C.c_char_p
     lib.pmg_strerror.argtypes = [C.c_int]
     lib.pmg_check_shape.argtypes = [C.POINTER(PmgShape), C.c_int]
+    lib.pmg_uses_cluster.argtypes = [C.POINTER(PmgShape), C.c_int, C.c_uint32]
     lib.pmg_workspace_bytes.argtypes = [C.POINTER(PmgShape), C.c_int, C.POINTER(C.c_size_t)]
     lib.pmg_decode.argtypes = [
         C.POINTER(PmgShape), C.POINTER(PmgWeights), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,

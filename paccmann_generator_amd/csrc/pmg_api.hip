@@ -28,6 +28,10 @@ size_t pmg_wgrad_partial_floats(const PmgDims& d);
 
 static size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
 
+// shapes the clustered forward may serve (pmg_fwdc_applicable decides per call): room for its
+// exchange buffers is laid out only then
+static bool cluster_shape(const PmgDims& d) { return d.L == 1 && d.H <= 512 && d.G <= 8 * (32 / (d.H / 16)); }
+
 static void make_layout(const PmgDims& d, int mode, PmgLayout* L) {
   memset(L, 0, sizeof(*L));
   size_t off = 0;
@@ -44,6 +48,7 @@ static void make_layout(const PmgDims& d, int mode, PmgLayout* L) {
   if (mode == PMG_MODE_DECODE) {
     L->H0 = take((size_t)H * d.Z);  // packed latent_to_hidden
     L->pack_end = off;
+    if (cluster_shape(d)) { L->CX = take(pmg_fwdc_cx_floats(d)); L->CXS = take(pmg_fwdc_sync_words(d)); }
     L->SB = take(2 * G * (size_t)d.SW);
   } else {
     L->WXt = take((size_t)d.NXT * 16 * H);
@@ -52,6 +57,7 @@ static void make_layout(const PmgDims& d, int mode, PmgLayout* L) {
       L->WIHt[l] = take(l == 0 ? (size_t)PMG_KS * 3 * H : 3 * H * H);
     }
     L->pack_end = off;
+    if (cluster_shape(d)) { L->CX = take(pmg_fwdc_cx_floats(d)); L->CXS = take(pmg_fwdc_sync_words(d)); }
     L->SB = take(T * G * (size_t)d.SW);
     for (int l = 0; l < d.L; ++l) {
       L->HH[l] = take(T * G * H * 16);
@@ -204,6 +210,28 @@ static void fill_fwd_common(FwdArgs* a, const PmgDims& d, const PmgLayout& lay, 
     a->BG[l] = base + lay.BG[l];
   }
   a->SB = base + lay.SB;
+  if (lay.CXS) {
+    a->CX = base + lay.CX;
+    a->CXS = reinterpret_cast<unsigned*>(base + lay.CXS);
+  }
+}
+
+extern "C" int pmg_uses_cluster(const pmg_shape* s, int mode, uint32_t flags) {
+  const int rc = pmg_check_shape(s, mode);
+  if (rc) return rc;
+  const PmgDims d = pmg_dims(s);
+  PmgLayout lay;
+  make_layout(d, mode, &lay);
+  FwdArgs a;
+  fill_fwd_common(&a, d, lay, reinterpret_cast<float*>(256));   // addresses are only compared with null
+  a.mode = (mode == PMG_MODE_DECODE) ? PMG_FWD_DECODE : PMG_FWD_TEACHER;
+  a.flags = flags;
+  return pmg_fwdc_applicable(&a) ? 1 : 0;
+}
+
+static void fill_extras(FwdArgs* a, const pmg_weights* w) {
+  a->w_ctrl = w->w_ctrl; a->b_ctrl = w->b_ctrl; a->w_push = w->w_push; a->b_push = w->b_push;
+  a->w_out = w->w_out; a->b_out = w->b_out;
 }
 
 extern "C" int pmg_decode(const pmg_shape* s, const pmg_weights* w, const float* latent, int start_tok,
@@ -226,6 +254,7 @@ extern "C" int pmg_decode(const pmg_shape* s, const pmg_weights* w, const float*
   FwdArgs a;
   fill_fwd_common(&a, d, lay, base);
   a.mode = PMG_FWD_DECODE;
+  fill_extras(&a, w);
   a.KL = pmg_fwd_stack_rows(&a);
   a.N = gen_len;
   a.start_tok = start_tok; a.stop_tok = stop_tok; a.temperature = temperature; a.flags = flags;
@@ -309,6 +338,8 @@ extern "C" int pmg_logprob_fwd(const pmg_shape* s, const pmg_weights* w, const i
   fill_fwd_common(&a, d, lay, base);
   fill_history(&a, d, lay, base);
   a.mode = PMG_FWD_TEACHER;
+  a.flags = flags;
+  fill_extras(&a, w);
   a.KL = pmg_fwd_stack_rows(&a);
   a.N = d.T - 1;
   a.h0 = h0; a.tok_in = tokens; a.logp_out = logp_out; a.h_out = h_out;

@@ -91,9 +91,18 @@ struct FwdArgs {
   float* GT[PMG_MAX_LAYERS];  // teacher: [T-1][G][UT][4][64][4]
   float* CT; float* PV; float* TP; float* PR;
   float* LP;               // teacher: [T-1][G][16] copy of logp for the backward's loss
+  // clustered forward (pmg_fwdc.hip): exchange buffers, counters, and the extras in torch layout
+  float* CX; unsigned* CXS;
+  const float* w_ctrl; const float* b_ctrl; const float* w_push; const float* b_push;
+  const float* w_out; const float* b_out;
 };
 
 hipError_t pmg_launch_fwd(const FwdArgs* a, hipStream_t st);
+// clustered forward for small batches (pmg_fwdc.hip); pmg_launch_fwd picks it by shape
+bool pmg_fwdc_applicable(const FwdArgs* a);
+hipError_t pmg_launch_fwdc(const FwdArgs* a, hipStream_t st);
+size_t pmg_fwdc_cx_floats(const PmgDims& d);
+size_t pmg_fwdc_sync_words(const PmgDims& d);
 size_t pmg_fwd_lds_bytes(const FwdArgs* a);
 int pmg_fwd_stack_rows(const FwdArgs* a);
 

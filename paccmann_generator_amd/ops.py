@@ -48,6 +48,16 @@ def workspace_budget(device=None) -> int:
     return int(min(WORKSPACE_BUDGET_BYTES, WORKSPACE_FREE_FRACTION * (free + cached)))
 
 
+# Small batches run on clustered kernels (include/pmg.h, pmg_uses_cluster).  False forces the
+# batch-partitioned kernels everywhere (A/B measurements; processes that share the GPU with another
+# one that launches clustered kernels).
+USE_CLUSTER = True
+
+
+def _cluster_flag() -> int:
+    return 0 if USE_CLUSTER else _ffi.PMG_FLAG_NO_CLUSTER
+
+
 def release_workspaces() -> None:
     """Kept for callers of the r01 interface: workspaces are per call now; this only returns
     torch's cached blocks to the driver."""
@@ -165,7 +175,7 @@ def _decode_op(latent: Tensor, params: Sequence[Tensor], w_l2h: Tensor, b_l2h: T
     tokens = torch.empty(B, gen_len, dtype=torch.int64, device=latent.device)
     lens = torch.empty(B, dtype=torch.int32, device=latent.device)
     wstruct, keep = _wstruct(params, d['L'], w_l2h, b_l2h)
-    flags = 0 if early_exit else _ffi.PMG_FLAG_NO_EARLY_EXIT
+    flags = (0 if early_exit else _ffi.PMG_FLAG_NO_EARLY_EXIT) | _cluster_flag()
     rc = _ffi.lib.pmg_decode(C.byref(shape), C.byref(wstruct), _ffi._ptr(latent), int(start_tok), int(stop_tok),
                              int(gen_len), float(temperature), int(seed), int(offset), int(seq_index_base),
                              flags, _ffi._ptr(tokens), _ffi._ptr(lens), _ffi._ptr(ws), _ffi.current_stream())
@@ -248,7 +258,7 @@ def _check_train_inputs(tokens: Tensor, h0: Tensor, d: dict):
 
 def _fwd_call(shape, wstruct, tokens, h0, logp, ws, flags=0):
     rc = _ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(tokens), _ffi._ptr(h0),
-                                   _ffi._ptr(logp), None, flags, _ffi._ptr(ws), _ffi.current_stream())
+                                   _ffi._ptr(logp), None, flags | _cluster_flag(), _ffi._ptr(ws), _ffi.current_stream())
     _ffi.check(rc, 'pmg_logprob_fwd')
 
 
@@ -449,7 +459,9 @@ class TrainSlice:
         self.ws = _alloc_ws(self.shape, _ffi.PMG_MODE_TRAIN, dev)
         self.wstruct, self._keep = _wstruct(self.params, d['L'])
         self.logp = torch.empty(T - 1, B, dtype=torch.float32, device=dev)
-        _fwd_call(self.shape, self.wstruct, self.tokens, self.h0, self.logp, self.ws)
+        # slices of a pipelined step run side by side on several streams: never the clustered kernels, whose
+        # cluster barriers need every member resident (include/pmg.h, PMG_FLAG_NO_CLUSTER)
+        _fwd_call(self.shape, self.wstruct, self.tokens, self.h0, self.logp, self.ws, _ffi.PMG_FLAG_NO_CLUSTER)
         self.grads = self.grad_h0 = self.loss = None
 
     def backward(self, reward: Tensor, scale: float) -> None:

@@ -18,3 +18,14 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     return torch.device('cuda:0')
+
+
+@pytest.fixture(params=['clustered', 'batch'])
+def forward_path(request):
+    """Runs a test twice: small batches on the clustered forward kernels (the default) and with them
+    switched off, so that the batch-partitioned kernels keep their small-shape coverage."""
+    from paccmann_generator_amd import ops
+    old = ops.USE_CLUSTER
+    ops.USE_CLUSTER = request.param == 'clustered'
+    yield request.param
+    ops.USE_CLUSTER = old

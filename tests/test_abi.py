@@ -21,7 +21,7 @@ def test_header_declares_the_expected_entry_points():
     assert declared_functions() == sorted([
         'pmg_abi_version', 'pmg_strerror', 'pmg_check_shape', 'pmg_workspace_bytes', 'pmg_decode',
         'pmg_logprob_fwd', 'pmg_reinforce_bwd', 'pmg_step', 'pmg_detokenize', 'pmg_decode_noalloc',
-        'pmg_noalloc_scratch_bytes', 'pmg_reinforce_bptt', 'pmg_reinforce_wgrad'])
+        'pmg_noalloc_scratch_bytes', 'pmg_reinforce_bptt', 'pmg_reinforce_wgrad', 'pmg_uses_cluster'])
 
 
 def test_library_exports_every_declared_symbol():
@@ -118,3 +118,19 @@ def test_default_library_has_no_ablation_switches():
     syms = subprocess.run(['nm', '-D', '--undefined-only', default], capture_output=True, text=True).stdout
     assert 'getenv' not in syms
     assert os.path.samefile(_ffi.LIB_PATH, default) or os.environ.get('PMG_LIB')
+
+
+def test_cluster_path_selection_by_shape():
+    """Which launches take the clustered small-batch kernels (include/pmg.h, pmg_uses_cluster)."""
+    from paccmann_generator_amd import _ffi
+    def uses(B, H, L=1, V=60, flags=0, mode=_ffi.PMG_MODE_DECODE, T=100):
+        s = _ffi.make_shape(B, T, H, 128, 50, 50, V, L, 256, 0)
+        return _ffi.lib.pmg_uses_cluster(C.byref(s), mode, flags)
+    assert uses(64, 256) == 1 and uses(64, 256, mode=_ffi.PMG_MODE_TRAIN, T=102) == 1      # BASELINE configs[0]
+    assert uses(256, 256) == 1 and uses(257, 256) == 0          # 16 clusters of 16 CUs fill the chip
+    assert uses(128, 512) == 1 and uses(129, 512) == 0          # conditional_generator.json:12 at hidden 512
+    assert uses(512, 128) == 1 and uses(96, 384) == 1 and uses(144, 384) == 0
+    assert uses(4096, 512) == 0                                  # configs[1]: batch-partitioned
+    assert uses(64, 256, L=2) == 0 and uses(64, 640) == 0 and uses(64, 256, V=300) == 0
+    assert uses(64, 256, flags=_ffi.PMG_FLAG_NO_CLUSTER) == 0
+    assert uses(64, 100) < 0

@@ -8,7 +8,7 @@ import torch
 
 from tests import parity as P
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('forward_path')]
 TOL = 1e-4
 MID = dict(embedding_size=32, stack_width=20, stack_depth=12, n_layers=1, latent_dim=64, pad_index=0, vocab_size=40)
 

@@ -9,7 +9,7 @@ import torch
 from tests import golden_util as GU
 from tests.parity import START, STOP, rel_err
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('forward_path')]
 TOL = 1e-4
 
 
