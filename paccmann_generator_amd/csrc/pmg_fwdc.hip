@@ -67,13 +67,28 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return copysignf(t, x);
 }
 
-// Cluster barrier; returns false (workgroup-uniform) when it gave up.  `okw`: one LDS word.
-__device__ __forceinline__ bool cluster_barrier(unsigned* ctr, const unsigned target, unsigned* status, int* okw) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's sc1 stores have been written through
+// Sum over the 16 lanes of a DPP row (every lane gets the total): four row rotations on the VALU
+// instead of four ds_bpermute round trips.
+__device__ __forceinline__ float row16_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));  // row_ror:8
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));  // row_ror:4
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xf, 0xf, false));  // row_ror:2
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return x;
+}
+
+// Cluster barrier in two halves, so that loads which do not depend on the exchange (the owners' extras
+// weights) can be issued between them and land while lane 0 polls.  arrive: every wave's sc1 stores
+// written through, workgroup barrier, lane 0 adds to the counter.  wait: lane 0 polls (bounded),
+// workgroup barrier; returns false (workgroup-uniform) when it gave up.  `okw`: one LDS word.
+__device__ __forceinline__ void cluster_arrive(unsigned* ctr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool cluster_wait(unsigned* ctr, const unsigned target, unsigned* status, int* okw) {
   if (threadIdx.x == 0) {
     int ok = 1;
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int spins = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       if (++spins > FC_SPIN_LIMIT || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
@@ -89,14 +104,14 @@ __device__ __forceinline__ bool cluster_barrier(unsigned* ctr, const unsigned ta
   return *okw != 0;
 }
 
-// MODE: PMG_FWD_DECODE or PMG_FWD_TEACHER.  One layer.
-template <int MODE>
+// MODE: PMG_FWD_DECODE or PMG_FWD_TEACHER.  One layer.  HM = H / 64: float4 per lane and extras row.
+template <int MODE, int HM>
 __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool teacher = (MODE == PMG_FWD_TEACHER);
   constexpr bool decode = (MODE == PMG_FWD_DECODE);
-  const int H = a.H, W = a.W, D = a.D, V = a.V, B = a.B, G = a.G, N = a.N, NX = a.NX;
-  const int KG = H / 16, C = KG;                 // members per cluster = unit tiles
+  constexpr int H = 64 * HM, KG = H / 16, C = KG;
+  const int W = a.W, D = a.D, V = a.V, B = a.B, G = a.G, N = a.N, NX = a.NX;                 // members per cluster = unit tiles
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = lane & 15, q = lane >> 4;
   // workgroup -> (cluster, member): clusters are dealt over the XCDs first
@@ -112,10 +127,12 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
   float* wl_hh = reinterpret_cast<float*>(smem);            // [3][KG][64][4] packed gate rows of the own units
   float* wl_is = wl_hh + 3 * KG * 256;                      // [3][4][64][4]  stack-top columns of W_ih
   float* red = wl_is + 3 * 4 * 256;                         // [8 waves][2][256] K-split partials
-  float* hrow = red + 8 * 2 * 256;                          // [H]   hidden state of the sequence being served
-  float* xex = hrow + H;                                    // [256] extras of that sequence
+  float* bxl = red + 8 * 2 * 256;                           // [256] extras bias (ctrl | push | out)
+  float* xex = bxl + 256;                                   // [256] extras of the sequence being served
   float* stk = xex + 256;                                   // [NOWN][2][D*W] own sequences' stacks (ping-pong)
   int* misc = reinterpret_cast<int*>(stk + (size_t)NOWN * 2 * DW);   // [0] barrier ok, [1..] scratch
+  float* gtl = reinterpret_cast<float*>(misc + 64);         // [V][3][16] token-table lines of the own units (if they fit)
+  const bool gt_lds = a.cluster_gtab_lds != 0;
 
   // ---- exchange buffers of this cluster
   const size_t cxs = (size_t)2 * H * 16 + 16 * 128;         // floats per cluster
@@ -125,7 +142,17 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
   unsigned* ctr = a.CXS + 32 + (size_t)g * 32;              // counter of this cluster (own 128-B line)
   unsigned* status = a.CXS;                                  // one word for the launch
   unsigned bars = 0;
-#define FC_BARRIER() (++bars, cluster_barrier(ctr, (unsigned)C * bars, status, misc))
+#define FC_ARRIVE() (++bars, cluster_arrive(ctr))
+#define FC_WAIT() cluster_wait(ctr, (unsigned)C * bars, status, misc)
+#ifdef PMG_PROFILE
+  // -DPMG_PROFILE build + PMG_DEBUG bit 0x8000: per-phase cycle counters of member 0 of cluster 0
+  const bool prof = (a.dbg & 0x8000) != 0 && g == 0 && cu == 0;
+  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#define FC_TICK(k) if (prof) { const long long tn_ = (long long)__builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; }
+#else
+#define FC_TICK(k)
+#endif
 
   // ---- resident weights: the packed forward operands of pmg_pack.hip, tiles 3*cu .. 3*cu+2
   {
@@ -136,6 +163,33 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
   }
   for (int i = tid; i < NOWN * 2 * DW; i += FC_THREADS) stk[i] = 0.0f;
   if (tid < 64) misc[tid] = 0;
+  if (gt_lds)
+    for (int idx = tid; idx < V * 48; idx += FC_THREADS) {
+      const int v = idx / 48, rem = idx - v * 48;
+      gtl[idx] = a.GTAB[(size_t)v * 3 * H + (size_t)(rem >> 4) * H + 16 * cu + (rem & 15)];
+    }
+  if (tid < 256) bxl[tid] = (tid < 3) ? a.b_ctrl[tid] : (tid < 3 + W) ? a.b_push[tid - 3] : (tid < NX) ? a.b_out[tid - 3 - W] : 0.0f;
+
+  // ---- owners' extras product [W_ctrl; W_push; W_out] h: 16 lanes per row, 32 rows at a time; the
+  // weights of the first RC rows of each 16-lane group live in registers and are (re)loaded between
+  // the two halves of barrier B, i.e. while the new hidden state is still on its way
+  constexpr int RC = 16 / HM;                    // rows per register chunk (RC * HM <= 16 float4)
+  const int l16 = tid & 15, rgrp = tid >> 4;
+  const int RX = (NX + 31) >> 5;                 // rows per 16-lane group
+  const int NCH = (RX + RC - 1) / RC;            // chunks (1 at hidden <= 256 and NX <= 128)
+  const bool owner = cu < 16;
+  f32x4 wreg[RC * HM];
+  auto load_chunk = [&](const int c) {
+#pragma unroll
+    for (int r = 0; r < RC; ++r) {
+      const int n = rgrp + 32 * (c * RC + r);
+      const float* wr = (n < 3) ? a.w_ctrl + (size_t)n * H
+                                : (n < 3 + W) ? a.w_push + (size_t)(n - 3) * H : a.w_out + (size_t)(n - 3 - W) * H;
+#pragma unroll
+      for (int m = 0; m < HM; ++m)
+        wreg[r * HM + m] = (n < NX) ? ld4(wr + 4 * l16 + 64 * m) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
 
   // ---- h0 of the own units for the 16 sequences (D layout: lane (b, q) holds units 4q..4q+3 of row b)
   f32x4 hown = {0.f, 0.f, 0.f, 0.f};             // wave 0 only: own slice of the current hidden state
@@ -168,13 +222,23 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
       for (int j = 0; j < 4; ++j) a.HH[0][((size_t)g * H + 16 * cu + 4 * q + j) * 16 + b] = hown[j];
     }
   }
-  bool ok = FC_BARRIER();                         // h0 of every member visible
+  FC_ARRIVE();
+  if (owner) load_chunk(0);
+  bool ok = FC_WAIT();                            // h0 of every member visible
+  float u0 = 0.f, u1 = 0.f;                       // the uniform of the next draw of each owned row (decode)
+  float pv0 = 0.f, pv1 = 0.f, top0 = 0.f, top1 = 0.f;   // wave 0: push value / new stack top of each owned row (history, deferred)
+  float* fm = reinterpret_cast<float*>(misc + 16);      // [2][4] stack controls of the owned rows
+  // deferred stack update: thread -> (row offset sd0, column sw), SDS rows apart (no division in the loop)
+  const int SDS = FC_THREADS / W;                 // W <= 64: at least 8 rows in flight
+  const int sd0 = tid / W, sw = (sd0 < SDS) ? tid - sd0 * W : W;
 
   // per owned sequence (k < NOWN): sampling state, identical in the lanes that serve it
   bool fin0 = false, fin1 = false;
   int mylen0 = N, mylen1 = N;
   const f32x4 bhn = (wave == 0) ? ld4(a.BG[0] + 3 * H + 16 * cu + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  FC_TICK(7)
+  f32x4 gr = {0.f, 0.f, 0.f, 0.f}, gz = gr, gn = gr, gvh = gr;    // wave 0, teacher: gates of this step (history)
   for (int i = 0; ok; ++i) {
     const __amdgpu_buffer_rsrc_t hin = (i & 1) ? hb1 : hb0, hout = (i & 1) ? hb0 : hb1;
     // ================================================================ owners: per-sequence work
@@ -188,31 +252,35 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
       const bool rowok = row < B;
       float* sold = stk + ((size_t)k * 2 + (i & 1)) * DW;
       float* snew = stk + ((size_t)k * 2 + ((i + 1) & 1)) * DW;
-      // ---- hidden state of sequence s out of the packed blocks: unit 16*kg + 4*kq + c <- lane s + 16*kq
-      for (int t = tid; t < H / 4; t += FC_THREADS) {
-        const int kg = t >> 2, kq = t & 3;
-        const float4 v = xld4(hin, (unsigned)(kg * 256 + (s + 16 * kq) * 4) * 4u);
-        *reinterpret_cast<float4*>(hrow + 16 * kg + 4 * kq) = v;
-      }
-      __syncthreads();
-      // ---- extras = [W_ctrl; W_push; W_out] h + b: 16 lanes per row, float4 along the reduction
+      // ---- extras of sequence s.  Every lane reads its slice of the hidden state straight out of the
+      // packed blocks (unit 16*kg + 4*kq + c sits in lane s + 16*kq of block kg): no staging, no barrier
       {
-        const int l16 = tid & 15;
-        for (int n = tid >> 4; n < NX; n += FC_THREADS / 16) {
-          const float* wr = (n < 3) ? a.w_ctrl + (size_t)n * H
-                                    : (n < 3 + W) ? a.w_push + (size_t)(n - 3) * H : a.w_out + (size_t)(n - 3 - W) * H;
-          float acc = 0.0f;
-          for (int k4 = 4 * l16; k4 < H; k4 += 64) {
-            const f32x4 wv = ld4(wr + k4), hv = ld4(hrow + k4);
-            acc = fmaf(wv[0], hv[0], acc); acc = fmaf(wv[1], hv[1], acc);
-            acc = fmaf(wv[2], hv[2], acc); acc = fmaf(wv[3], hv[3], acc);
-          }
+        f32x4 hv[HM];
 #pragma unroll
-          for (int o = 8; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 16);
-          if (l16 == 0) xex[n] = acc + ((n < 3) ? a.b_ctrl[n] : (n < 3 + W) ? a.b_push[n - 3] : a.b_out[n - 3 - W]);
+        for (int m = 0; m < HM; ++m) {
+          const float4 v = xld4(hin, (unsigned)((((l16 >> 2) + 4 * m) * 64 + s + 16 * (l16 & 3)) * 4) * 4u);
+          hv[m] = (f32x4){v.x, v.y, v.z, v.w};
         }
+        for (int c = 0; c < NCH; ++c) {
+          if (c > 0) load_chunk(c);
+#pragma unroll
+          for (int r = 0; r < RC; ++r) {
+            const int n = rgrp + 32 * (c * RC + r);
+            float acc = 0.0f;
+#pragma unroll
+            for (int m = 0; m < HM; ++m) {
+              acc = fmaf(wreg[r * HM + m][0], hv[m][0], acc); acc = fmaf(wreg[r * HM + m][1], hv[m][1], acc);
+              acc = fmaf(wreg[r * HM + m][2], hv[m][2], acc); acc = fmaf(wreg[r * HM + m][3], hv[m][3], acc);
+            }
+            acc = row16_sum(acc);
+            if (l16 == 0 && n < NX) xex[n] = acc + bxl[n];
+          }
+        }
+        if (NCH > 1 && k + 1 < NOWN) load_chunk(0);   // registers hold the last chunk: first one back for the next sequence
       }
+      FC_TICK(0)
       __syncthreads();
+      FC_TICK(1)
       // ---- consume the logits of step i-1 (wave 0, lanes 0..31: entry v sits in lane v & 31)
       int tok = teacher ? ((rowok && i < N + 1) ? min(max((int)a.tok_in[(size_t)min(i, N) * B + row], 0), V - 1) : 0) : a.start_tok;
       if (i >= 1 && wave == 0 && lane < 32) {
@@ -254,36 +322,34 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
             for (int v = l5; v < V; v += 32) m = fmaxf(m, lg[v] / T);
 #pragma unroll
             for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 32));
-            const float u = pmg_uniform(a.seed, (uint64_t)(a.seq_base + row), a.offset + (uint64_t)(i - 1));
-            const int nslot = (V + 31) >> 5;
+            const float u = k ? u1 : u0;          // pmg_uniform(seed, global row, offset + i - 1), formed under barrier B
+            // running CDF: slot ks holds entries 32ks..32ks+31, one per lane (3+W+V <= 256 on this path)
+            float cdf[8];
             float carry = 0.0f;
-#pragma unroll 1
-            for (int ks = 0; ks < nslot; ++ks) {
-              const int v = 32 * ks + l5;
-              float e = (v < V) ? __expf(lg[v] / T - m) : 0.0f;
 #pragma unroll
-              for (int o = 1; o <= 16; o <<= 1) {
-                const float t = __shfl_up(e, o, 32);
-                if (l5 >= o) e += t;
+            for (int ks = 0; ks < 8; ++ks) {
+              cdf[ks] = 0.0f;
+              if (32 * ks < V) {
+                const int v = 32 * ks + l5;
+                float e = (v < V) ? __expf(lg[v] / T - m) : 0.0f;
+#pragma unroll
+                for (int o = 1; o <= 16; o <<= 1) {
+                  const float t = __shfl_up(e, o, 32);
+                  if (l5 >= o) e += t;
+                }
+                cdf[ks] = carry + e;
+                carry = __shfl(cdf[ks], 31, 32);
               }
-              carry = __shfl(carry + e, 31, 32);
             }
             const float target = u * carry;
-            carry = 0.0f;
             tok = -1;
-#pragma unroll 1
-            for (int ks = 0; ks < nslot; ++ks) {
-              const int v = 32 * ks + l5;
-              float e = (v < V) ? __expf(lg[v] / T - m) : 0.0f;
 #pragma unroll
-              for (int o = 1; o <= 16; o <<= 1) {
-                const float t = __shfl_up(e, o, 32);
-                if (l5 >= o) e += t;
+            for (int ks = 0; ks < 8; ++ks) {
+              if (32 * ks < V) {
+                const int v = 32 * ks + l5;
+                const unsigned mk = (unsigned)__ballot((v < V) && (target < cdf[ks]));
+                if (tok < 0 && mk) tok = 32 * ks + (__ffs(mk) - 1);
               }
-              const float cdf = carry + e;
-              const unsigned mk = (unsigned)__ballot((v < V) && (target < cdf));
-              if (tok < 0 && mk) tok = 32 * ks + (__ffs(mk) - 1);
-              carry = __shfl(cdf, 31, 32);
             }
             if (tok < 0) tok = V - 1;
           }
@@ -295,63 +361,93 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
         misc[2] = tok; misc[3] = rowok ? 0 : 1;
       }
       __syncthreads();
+      FC_TICK(2)
       if (i < N) {
         tok = misc[2];
-        // ---- stack controls, push value, stack update (whole stack of this sequence is in LDS)
+        // ---- stack controls; ROW 0 of the new stack (= the stack top the gates need) and the record
+        // go out first: the rest of the update and every history store wait until this member has
+        // arrived at barrier A (below), off the chain the other members wait on
         const float c0 = xex[0], c1 = xex[1], c2 = xex[2];
         const float m = fmaxf(c0, fmaxf(c1, c2));
         const float e0 = __expf(c0 - m), e1 = __expf(c1 - m), e2 = __expf(c2 - m);
         const float inv = 1.0f / ((e0 + e1) + e2);
         const float apush = e0 * inv, apop = e1 * inv, anoop = e2 * inv;
-        // rows that hold data: d <= min(i, D-1) after this update (row d is zero until step d)
-        const int dhi = (i < D - 1) ? i : D - 1;
-        for (int idx = tid; idx < (dhi + 1) * W; idx += FC_THREADS) {
-          const int d = idx / W, w = idx - d * W;
-          const float cur = sold[idx];
-          const float prev = (d == 0) ? fast_tanh(xex[3 + w]) : sold[idx - W];
-          const float nxt = (d + 1 < D) ? sold[idx + W] : 0.0f;
-          const float nw = anoop * cur + apush * prev + apop * nxt;
-          snew[idx] = nw;
-          if (teacher) {
-            // history the BPTT reads: only rows that can still reach a stack top (pmg_fwd.hip, "live rows")
-            if (d <= N - 1 - i) a.SB[((size_t)(i + 1) * G + g) * a.SW + (size_t)idx * 16 + s] = nw;
-            if (d == 0) {
-              a.PV[((size_t)i * G + g) * 1024 + w * 16 + s] = prev;
-              a.TP[((size_t)i * G + g) * 2048 + w * 16 + s] = nw;
-            }
-          }
-        }
-        if (teacher) {
-          if (tid < 3) a.CT[((size_t)i * G + g) * 64 + tid * 16 + s] = (tid == 0) ? apush : (tid == 1) ? apop : anoop;
-          // one-hot rows of the fed token behind the stack-top rows (weight-gradient B operand, V <= 64)
-          if (tid >= 64 && tid < 128)
-            a.TP[((size_t)i * G + g) * 2048 + (size_t)tid * 16 + s] = (rowok && tok == tid - 64) ? 1.0f : 0.0f;
-        }
-        __syncthreads();
-        // ---- publish: stack top (zero padded to 64), next input token, finished flag; two store
-        // instructions of wave 0, each writing two whole 128-B lines
         if (wave == 0) {
-          const float top = (lane < W) ? snew[lane] : 0.0f;
+          float top = 0.0f, pv = 0.0f;
+          if (lane < W) {
+            pv = fast_tanh(xex[3 + lane]);
+            const float nxt = (1 < D) ? sold[W + lane] : 0.0f;
+            top = anoop * sold[lane] + apush * pv + apop * nxt;
+            snew[lane] = top;
+          }
           xst1(rec, (unsigned)(s * 128 + lane) * 4u, top);
           const float meta = (lane == 0) ? __int_as_float(tok) : (lane == 1) ? __int_as_float(misc[3]) : 0.0f;
           xst1(rec, (unsigned)(s * 128 + 64 + lane) * 4u, meta);
+          if (k) { pv1 = pv; top1 = top; } else { pv0 = pv; top0 = top; }
+          if (lane == 0) { fm[4 * k] = apush; fm[4 * k + 1] = apop; fm[4 * k + 2] = anoop; misc[8 + k] = tok; }
         }
       }
-      __syncthreads();
+      if (k + 1 < NOWN) __syncthreads();         // xex is reused by the next owned sequence
     }
+    FC_TICK(3)
     if (i == N) break;
-    if (!(ok = FC_BARRIER())) break;             // A: tokens and stack tops of all 16 sequences visible
+    FC_ARRIVE();
+    // ---- deferred owner work, under the wait of barrier A: stack rows >= 1 and the teacher history
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int s = cu + k * C;
+      if (k >= NOWN || s >= 16) break;
+      const bool rowok = row0 + s < B;
+      const float* sold = stk + ((size_t)k * 2 + (i & 1)) * DW;
+      float* snew = stk + ((size_t)k * 2 + ((i + 1) & 1)) * DW;
+      const float apush = fm[4 * k], apop = fm[4 * k + 1], anoop = fm[4 * k + 2];
+      // rows that hold data after this update: d <= min(i, D-1) (row d is zero until step d)
+      const int dhi = (i < D - 1) ? i : D - 1;
+      for (int d = 1 + sd0; d <= dhi; d += SDS) {       // thread (sd0, sw): column sw of rows 1 + sd0 + j*SDS
+        if (sw < W) {
+          const int idx = d * W + sw;
+          const float nxt = (d + 1 < D) ? sold[idx + W] : 0.0f;
+          const float nw = anoop * sold[idx] + apush * sold[idx - W] + apop * nxt;
+          snew[idx] = nw;
+          // history the BPTT reads: only rows that can still reach a stack top (pmg_fwd.hip, "live rows")
+          if (teacher && d <= N - 1 - i) a.SB[((size_t)(i + 1) * G + g) * a.SW + (size_t)idx * 16 + s] = nw;
+        }
+      }
+      if (teacher) {
+        if (wave == 0 && lane < W) {
+          const float pv = k ? pv1 : pv0, top = k ? top1 : top0;
+          a.SB[((size_t)(i + 1) * G + g) * a.SW + (size_t)lane * 16 + s] = top;
+          a.PV[((size_t)i * G + g) * 1024 + lane * 16 + s] = pv;
+          a.TP[((size_t)i * G + g) * 2048 + lane * 16 + s] = top;
+        }
+        if (tid >= 128 && tid < 131)
+          a.CT[((size_t)i * G + g) * 64 + (tid - 128) * 16 + s] = (tid == 128) ? apush : (tid == 129) ? apop : anoop;
+        // one-hot rows of the fed token behind the stack-top rows (weight-gradient B operand, V <= 64)
+        if (tid >= 64 && tid < 128)
+          a.TP[((size_t)i * G + g) * 2048 + (size_t)tid * 16 + s] = (rowok && misc[8 + k] == tid - 64) ? 1.0f : 0.0f;
+      }
+    }
+    if (!(ok = FC_WAIT())) break;                // A: tokens and stack tops of all 16 sequences visible
 
+    FC_TICK(4)
     // ================================================================ members: gates of the own 16 units
     {
       // K split: waves 0-3 carry the r and z tiles, waves 4-7 the n tile (input and hidden part apart)
       const int kw = wave & 3;
-      const int kq0 = kw * (KG / 4), kq1 = kq0 + KG / 4;
+      const int kq0 = kw * (KG / 4);
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      // every exchanged operand of this wave is requested up front: one L2 round trip, not one per k group
       const float4 xt = xld4(rec, (unsigned)(b * 128 + 16 * kw + 4 * q) * 4u);       // stack-top k group kw
+      float4 xs[HM];
+#pragma unroll
+      for (int m = 0; m < HM; ++m) xs[m] = xld4(hin, (unsigned)((kq0 + m) * 256 + lane * 4) * 4u);
+      float tkf = 0.0f;
+      if (wave == 0) tkf = xld1(rec, (unsigned)(b * 128 + 64) * 4u);                  // token fed to row b at this step
       if (wave < 4) {
-        for (int kg = kq0; kg < kq1; ++kg) {
-          const float4 x = xld4(hin, (unsigned)(kg * 256 + lane * 4) * 4u);
+#pragma unroll
+        for (int m = 0; m < HM; ++m) {
+          const int kg = kq0 + m;
+          const float4 x = xs[m];
           const f32x4 wr = ld4(wl_hh + (size_t)(0 * KG + kg) * 256 + lane * 4), wz = ld4(wl_hh + (size_t)(1 * KG + kg) * 256 + lane * 4);
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0], x.x, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[0], x.x, acc1, 0, 0, 0);
@@ -372,8 +468,10 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[3], xt.w, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[3], xt.w, acc1, 0, 0, 0);
       } else {
-        for (int kg = kq0; kg < kq1; ++kg) {      // acc1 = W_hn h
-          const float4 x = xld4(hin, (unsigned)(kg * 256 + lane * 4) * 4u);
+#pragma unroll
+        for (int m = 0; m < HM; ++m) {            // acc1 = W_hn h
+          const int kg = kq0 + m;
+          const float4 x = xs[m];
           const f32x4 wn = ld4(wl_hh + (size_t)(2 * KG + kg) * 256 + lane * 4);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[0], x.x, acc1, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[1], x.y, acc1, 0, 0, 0);
@@ -388,15 +486,15 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
       }
       st4(red + (size_t)(wave * 2 + 0) * 256 + lane * 4, acc0);
       st4(red + (size_t)(wave * 2 + 1) * 256 + lane * 4, acc1);
-      // tokens and finished flags of the 16 sequences (wave 0 needs its row's token; everyone the flags)
-      int alld = 1;
-      if (decode) {
-        for (int s2 = 0; s2 < 16; ++s2) alld &= (__float_as_int(xld1(rec, (unsigned)(s2 * 128 + 65) * 4u)) != 0);
-        if (a.flags & PMG_FLAG_NO_EARLY_EXIT) alld = 0;
-      } else {
-        alld = 0;
+      // finished flags of the 16 sequences: ONE load per lane of wave 1 (lane s reads the flag of sequence
+      // s), combined by a ballot and handed to everybody through LDS behind the barrier below
+      if (decode && wave == 1) {
+        const int fl = (lane < 16) ? __float_as_int(xld1(rec, (unsigned)(lane * 128 + 65) * 4u)) : 1;
+        const int all1 = __all(fl != 0);
+        if (lane == 0) misc[4] = (all1 && !(a.flags & PMG_FLAG_NO_EARLY_EXIT)) ? 1 : 0;
       }
       __syncthreads();
+      const int alld = decode ? misc[4] : 0;
       if (wave == 0) {
         f32x4 vr = {0.f, 0.f, 0.f, 0.f}, vz = vr, vi = vr, vh = vr;
 #pragma unroll
@@ -406,9 +504,15 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
           vi += ld4(red + (size_t)((wv + 4) * 2 + 0) * 256 + lane * 4);
           vh += ld4(red + (size_t)((wv + 4) * 2 + 1) * 256 + lane * 4);
         }
-        const int tk = __float_as_int(xld1(rec, (unsigned)(b * 128 + 64) * 4u));      // token fed to row b at this step
-        const float* gt = a.GTAB + (size_t)tk * 3 * H + 16 * cu + 4 * q;
-        vr += ld4(gt); vz += ld4(gt + H); vi += ld4(gt + 2 * H); vh += bhn;
+        const int tk = __float_as_int(tkf);
+        if (gt_lds) {
+          const float* gt = gtl + (size_t)tk * 48 + 4 * q;
+          vr += ld4(gt); vz += ld4(gt + 16); vi += ld4(gt + 32);
+        } else {
+          const float* gt = a.GTAB + (size_t)tk * 3 * H + 16 * cu + 4 * q;
+          vr += ld4(gt); vz += ld4(gt + H); vi += ld4(gt + 2 * H);
+        }
+        vh += bhn;
         f32x4 r, z, n, hn;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -419,13 +523,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
         }
         hown = hn;
         if (!alld) xst4(hout, (unsigned)(cu * 256 + lane * 4) * 4u, hn);
-        if (teacher) {
-          float* gp = a.GT[0] + (((size_t)i * G + g) * KG + cu) * 1024 + lane * 4;
-          st4(gp, r); st4(gp + 256, z); st4(gp + 512, n); st4(gp + 768, vh);
-          float* hh = a.HH[0] + (((size_t)(i + 1) * G + g) * H + 16 * cu + 4 * q) * 16 + b;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) hh[j * 16] = hn[j];
-        }
+        if (teacher) { gr = r; gz = z; gn = n; gvh = vh; }      // history: stored after the arrive of barrier B
       }
       if (alld) {
         // every row of this cluster has emitted stop_tok: owners fill their rows' tails and all leave
@@ -437,8 +535,31 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
         break;
       }
     }
-    if (!(ok = FC_BARRIER())) break;             // B: the new hidden state of every member visible
+    FC_TICK(5)
+    FC_ARRIVE();
+    if (teacher && wave == 0) {
+      float* gp = a.GT[0] + (((size_t)i * G + g) * KG + cu) * 1024 + lane * 4;
+      st4(gp, gr); st4(gp + 256, gz); st4(gp + 512, gn); st4(gp + 768, gvh);
+      float* hh = a.HH[0] + (((size_t)(i + 1) * G + g) * H + 16 * cu + 4 * q) * 16 + b;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hh[j * 16] = hown[j];
+    }
+    if (owner) {
+      // under the wait: what the next step's owner phase needs and the exchange does not carry
+      load_chunk(0);
+      if (decode && wave == 0) {
+        u0 = pmg_uniform(a.seed, (uint64_t)(a.seq_base + row0 + cu), a.offset + (uint64_t)i);
+        if (NOWN > 1) u1 = pmg_uniform(a.seed, (uint64_t)(a.seq_base + row0 + cu + C), a.offset + (uint64_t)i);
+      }
+    }
+    if (!(ok = FC_WAIT())) break;                // B: the new hidden state of every member visible
+    FC_TICK(6)
   }
+#ifdef PMG_PROFILE
+  if (prof && tid == 0)
+    printf("fwdc member 0 cycles: gather-h %lld extras %lld logits %lld stack+publish %lld barrierA %lld gates %lld barrierB %lld (init %lld)\n",
+           tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7]);
+#endif
 
   // ---------------------------------------------------------------- epilogue
   if (!ok) {
@@ -460,9 +581,14 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
   if (a.h_out != nullptr && wave == 0 && row0 + b < B) st4(a.h_out + (size_t)(row0 + b) * H + 16 * cu + 4 * q, hown);
 }
 
-size_t fwdc_lds_bytes(const FwdArgs* a) {
+size_t fwdc_lds_base_bytes(const FwdArgs* a) {
   const int KG = a->H / 16, nown = (16 + KG - 1) / KG;
-  return ((size_t)3 * KG * 256 + 3 * 4 * 256 + 8 * 2 * 256 + a->H + 256 + (size_t)nown * 2 * a->D * a->W + 64) * sizeof(float);
+  return ((size_t)3 * KG * 256 + 3 * 4 * 256 + 8 * 2 * 256 + 256 + 256 + (size_t)nown * 2 * a->D * a->W + 64) * sizeof(float);
+}
+
+bool fwdc_gtab_fits(const FwdArgs* a) { return fwdc_lds_base_bytes(a) + (size_t)a->V * 48 * 4 <= (size_t)160 * 1024; }
+size_t fwdc_lds_bytes(const FwdArgs* a) {
+  return fwdc_lds_base_bytes(a) + (fwdc_gtab_fits(a) ? (size_t)a->V * 48 * 4 : 0);
 }
 
 }  // namespace
@@ -480,10 +606,13 @@ bool pmg_fwdc_applicable(const FwdArgs* a) {
   if (a->L != 1 || a->H > 512 || a->NX > 256 || a->CX == nullptr) return false;
   const int C = a->H / 16;
   if (a->G > 8 * (32 / C)) return false;
-  return fwdc_lds_bytes(a) <= (size_t)160 * 1024;
+  return fwdc_lds_base_bytes(a) <= (size_t)160 * 1024;
 }
 
-hipError_t pmg_launch_fwdc(const FwdArgs* a, hipStream_t st) {
+hipError_t pmg_launch_fwdc(const FwdArgs* a0, hipStream_t st) {
+  FwdArgs args = *a0;
+  args.cluster_gtab_lds = fwdc_gtab_fits(a0) ? 1 : 0;
+  const FwdArgs* a = &args;
   const int C = a->H / 16;
   size_t lds = fwdc_lds_bytes(a);
   if (lds < (size_t)81 * 1024) lds = (size_t)81 * 1024;     // more than half a CU: one workgroup per CU
@@ -491,15 +620,23 @@ hipError_t pmg_launch_fwdc(const FwdArgs* a, hipStream_t st) {
   hipError_t e = hipMemsetAsync(a->CXS, 0, (size_t)32 * (1 + a->G) * sizeof(unsigned), st);
   if (e != hipSuccess) return e;
   const int grid = 8 * C * ((a->G + 7) / 8);
-  static std::atomic<unsigned long long> done_d{0}, done_t{0};
-  if (a->mode == PMG_FWD_DECODE) {
-    e = pmg_full_lds_once(reinterpret_cast<const void*>(pmg_fwdc_kernel<PMG_FWD_DECODE>), &done_d);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(pmg_fwdc_kernel<PMG_FWD_DECODE>, dim3(grid), dim3(FC_THREADS), lds, st, *a);
-  } else {
-    e = pmg_full_lds_once(reinterpret_cast<const void*>(pmg_fwdc_kernel<PMG_FWD_TEACHER>), &done_t);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(pmg_fwdc_kernel<PMG_FWD_TEACHER>, dim3(grid), dim3(FC_THREADS), lds, st, *a);
+#define FC_LAUNCH(MODE_, HM_)                                                                              \
+  {                                                                                                        \
+    static std::atomic<unsigned long long> done{0};                                                        \
+    e = pmg_full_lds_once(reinterpret_cast<const void*>(pmg_fwdc_kernel<MODE_, HM_>), &done);              \
+    if (e != hipSuccess) return e;                                                                         \
+    hipLaunchKernelGGL((pmg_fwdc_kernel<MODE_, HM_>), dim3(grid), dim3(FC_THREADS), lds, st, *a);          \
+    return hipGetLastError();                                                                              \
   }
-  return hipGetLastError();
+#define FC_LAUNCH_H(MODE_)                        \
+  switch (a->H) {                                 \
+    case 128: FC_LAUNCH(MODE_, 2)                 \
+    case 256: FC_LAUNCH(MODE_, 4)                 \
+    case 384: FC_LAUNCH(MODE_, 6)                 \
+    case 512: FC_LAUNCH(MODE_, 8)                 \
+  }
+  if (a->mode == PMG_FWD_DECODE) FC_LAUNCH_H(PMG_FWD_DECODE) else FC_LAUNCH_H(PMG_FWD_TEACHER)
+#undef FC_LAUNCH_H
+#undef FC_LAUNCH
+  return hipErrorInvalidValue;
 }

@@ -93,6 +93,7 @@ struct FwdArgs {
   float* LP;               // teacher: [T-1][G][16] copy of logp for the backward's loss
   // clustered forward (pmg_fwdc.hip): exchange buffers, counters, and the extras in torch layout
   float* CX; unsigned* CXS;
+  int cluster_gtab_lds;    // set by pmg_launch_fwdc: the token-table lines of a member's units fit its LDS
   const float* w_ctrl; const float* b_ctrl; const float* w_push; const float* b_push;
   const float* w_out; const float* b_out;
 };
