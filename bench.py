@@ -218,7 +218,7 @@ def time_phases(learner, cfg, latent, rewards, B, reps=3):
 
     def f_bptt():
         _ffi.check(_ffi.lib.pmg_reinforce_bptt(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(rewards),
-                                               1.0 / B, _ffi._ptr(gh0), _ffi._ptr(ws), st), 'bptt')
+                                               1.0 / B, ops._cluster_flag(), _ffi._ptr(gh0), _ffi._ptr(ws), st), 'bptt')
 
     def f_wgrad():
         _ffi.check(_ffi.lib.pmg_reinforce_wgrad(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), 0,

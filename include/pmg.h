@@ -39,7 +39,7 @@ extern "C" {
                                      pmg_logprob_fwd call on it (same weights, same model dimensions; B and T
                                      may differ): skip the packing kernels.  For batches run in chunks. */
 
-#define PMG_FLAG_NO_CLUSTER 32u   /* decode / logprob_fwd: never take the clustered small-batch kernels (see below).
+#define PMG_FLAG_NO_CLUSTER 32u   /* decode / logprob_fwd / reinforce_bwd / reinforce_bptt: never take the clustered small-batch kernels (see below).
                                      Pass it on launches that may run CONCURRENTLY with another pmg_decode /
                                      pmg_logprob_fwd on the same GPU (other streams or processes). */
 
@@ -190,11 +190,14 @@ int pmg_reinforce_bwd(const pmg_shape* s, const pmg_weights* w, const int64_t* t
  * throughput-bound contraction over all B*T tokens.
  *   pmg_reinforce_bptt : walks time backwards from the trajectory pmg_logprob_fwd left in `ws`; writes
  *                        grad_h0 and, into `ws`, the per-step gate / extras gradient slabs and the
- *                        loss partials.
+ *                        loss partials; flags: 0 or PMG_FLAG_NO_CLUSTER (small batches run on clusters
+ *                        of workgroups like the forward, see pmg_uses_cluster; a launch that gave up
+ *                        leaves NaN in grad_h0 and in the loss).
  *   pmg_reinforce_wgrad: contracts those slabs with the saved activations into grad_out (every
  *                        decoder parameter) and loss_out; flags: 0 or PMG_FLAG_ACCUMULATE. */
 int pmg_reinforce_bptt(const pmg_shape* s, const pmg_weights* w, const int64_t* tokens,
-                       const float* reward, float scale, float* grad_h0, void* ws, pmg_stream stream);
+                       const float* reward, float scale, uint32_t flags, float* grad_h0, void* ws,
+                       pmg_stream stream);
 int pmg_reinforce_wgrad(const pmg_shape* s, const pmg_weights* w, const int64_t* tokens, uint32_t flags,
                         const pmg_grads* grad_out, float* loss_out, void* ws, pmg_stream stream);
 

@@ -84,8 +84,8 @@ def _load():
         C.POINTER(PmgShape), C.POINTER(PmgWeights), C.c_void_p, C.c_void_p, C.c_float, C.c_uint32,
         C.POINTER(PmgGrads), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pmg_reinforce_bptt.argtypes = [
-        C.POINTER(PmgShape), C.POINTER(PmgWeights), C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
-        C.c_void_p]
+        C.POINTER(PmgShape), C.POINTER(PmgWeights), C.c_void_p, C.c_void_p, C.c_float, C.c_uint32, C.c_void_p,
+        C.c_void_p, C.c_void_p]
     lib.pmg_reinforce_wgrad.argtypes = [
         C.POINTER(PmgShape), C.POINTER(PmgWeights), C.c_void_p, C.c_uint32, C.POINTER(PmgGrads), C.c_void_p,
         C.c_void_p, C.c_void_p]

@@ -57,7 +57,11 @@ static void make_layout(const PmgDims& d, int mode, PmgLayout* L) {
       L->WIHt[l] = take(l == 0 ? (size_t)PMG_KS * 3 * H : 3 * H * H);
     }
     L->pack_end = off;
-    if (cluster_shape(d)) { L->CX = take(pmg_fwdc_cx_floats(d)); L->CXS = take(pmg_fwdc_sync_words(d)); }
+    if (cluster_shape(d)) {   // one exchange region serves the forward, then the backward
+      const size_t f = pmg_fwdc_cx_floats(d), b = pmg_bwdc_cx_floats(d);
+      L->CX = take(f > b ? f : b);
+      L->CXS = take(pmg_fwdc_sync_words(d));
+    }
     L->SB = take(T * G * (size_t)d.SW);
     for (int l = 0; l < d.L; ++l) {
       L->HH[l] = take(T * G * H * 16);
@@ -389,7 +393,8 @@ static int bwd_setup(const pmg_shape* s, const pmg_weights* w, const int64_t* to
 }
 
 extern "C" int pmg_reinforce_bptt(const pmg_shape* s, const pmg_weights* w, const int64_t* tokens,
-                                  const float* reward, float scale, float* grad_h0, void* ws, pmg_stream stream) {
+                                  const float* reward, float scale, uint32_t flags, float* grad_h0, void* ws,
+                                  pmg_stream stream) {
   PmgDims d;
   PmgLayout lay;
   float* base = nullptr;
@@ -415,6 +420,11 @@ extern "C" int pmg_reinforce_bptt(const pmg_shape* s, const pmg_weights* w, cons
   a.LP = base + lay.LP;
   a.DX = base + lay.DX; a.DS = base + lay.DS; a.DHC = base + lay.DHC; a.grad_h0 = grad_h0;
   a.LOSSP = base + lay.LOSSP;
+  a.flags = flags;
+  if (lay.CXS) {
+    a.CX = base + lay.CX;
+    a.CXS = reinterpret_cast<unsigned*>(base + lay.CXS);
+  }
   HIPCHK(pmg_launch_bwd(&a, st));
   return PMG_OK;
 }
@@ -447,7 +457,7 @@ extern "C" int pmg_reinforce_bwd(const pmg_shape* s, const pmg_weights* w, const
   if (s)
     for (int l = 0; l < s->L && l < PMG_MAX_LAYERS; ++l)
       if (!grad_out->w_ih[l] || !grad_out->w_hh[l] || !grad_out->b_ih[l] || !grad_out->b_hh[l]) return PMG_E_NULL;
-  int rc = pmg_reinforce_bptt(s, w, tokens, reward, scale, grad_h0, ws, stream);
+  int rc = pmg_reinforce_bptt(s, w, tokens, reward, scale, flags, grad_h0, ws, stream);
   if (rc) return rc;
   return pmg_reinforce_wgrad(s, w, tokens, flags, grad_out, loss_out, ws, stream);
 }

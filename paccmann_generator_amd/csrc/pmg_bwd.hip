@@ -844,6 +844,8 @@ static hipError_t launch_bwd_u(const BwdArgs* a, hipStream_t st) {
 }
 
 hipError_t pmg_launch_bwd(const BwdArgs* a, hipStream_t st) {
+  // small batches: the hidden-partitioned form (a cluster of H/16 CUs per 16 sequences), same results
+  if (pmg_bwdc_applicable(a)) return pmg_launch_bwdc(a, st);
   switch (a->H) {
     case 128: return launch_bwd_u<1>(a, st);
     case 256: return launch_bwd_u<2>(a, st);

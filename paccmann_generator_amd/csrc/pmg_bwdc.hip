@@ -1,0 +1,421 @@
+// Clustered ("hidden-partitioned") reward-weighted BPTT for SMALL batches: the counterpart of
+// pmg_fwdc.hip for the recurrent half of rl_loss.backward() (reference: reinforce_omics.py:335), same
+// arithmetic, same outputs (grad_h0, DG / DX gradient slabs for pmg_wgrad.hip, loss partial) as
+// pmg_bwd.hip, whose header gives the per-step algebra (restated in oracle/fused_model.py).
+//
+// A cluster of C = H/16 workgroups (one per CU) walks the 16 sequences of a row group backwards in
+// time.  Member c owns hidden units 16c..16c+15 for all 16 sequences: it carries their hidden-state
+// gradient, runs the GRU cell backward on them and keeps, resident in LDS, the 16 rows of W_hh^T, the
+// own 48 gate rows' part of W_ih[:, E:]^T and the 16 rows of [W_ctrl; W_push; W_out]^T that produce
+// those units (all three copied from the transposed packs of pmg_pack.hip).  Member s also owns
+// sequence s for what is per sequence: the stack backward (the whole stack gradient lives in its LDS),
+// control and push gradients, dlogits, the loss.  Per reverse step p, two exchanges:
+//   members: cell backward of the own units -> publish {dr, dz, dghn blocks; partial dtop}   | barrier A
+//   owners : dtop = sum of the C partials -> stack backward -> dx = [dctrl | dpush | dlogits] -> publish | barrier B
+//            (members form W_hh^T [dr; dz; dghn] for their units under the wait of barrier B)
+//   members: carry = z * dh + W_hh^T dgh + [W_ctrl; W_push; W_out]^T dx  (own units)
+// Hand-offs, barriers, residency rule and the bounded polls are those of pmg_fwdc.hip.
+#include "pmg_kernels.h"
+
+namespace {
+
+#define BC_THREADS 512
+#define BC_SPIN_LIMIT 3000000
+
+typedef unsigned bc_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 ld4(const float* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  f32x4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r;
+}
+__device__ __forceinline__ void st4(float* p, const f32x4 v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ f32x4 xld4(const __amdgpu_buffer_rsrc_t r, unsigned voff) {
+  const bc_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 16);
+  f32x4 o; o.x = __uint_as_float(v.x); o.y = __uint_as_float(v.y); o.z = __uint_as_float(v.z); o.w = __uint_as_float(v.w);
+  return o;
+}
+__device__ __forceinline__ float xld1(const __amdgpu_buffer_rsrc_t r, unsigned voff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 16));
+}
+__device__ __forceinline__ void xst4(const __amdgpu_buffer_rsrc_t r, unsigned voff, const f32x4 h) {
+  bc_u32x4 u;
+  u.x = __float_as_uint(h[0]); u.y = __float_as_uint(h[1]); u.z = __float_as_uint(h[2]); u.w = __float_as_uint(h[3]);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, 0, 16);
+}
+__device__ __forceinline__ void xst1(const __amdgpu_buffer_rsrc_t r, unsigned voff, const float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, 0, 16);
+}
+
+__device__ __forceinline__ void cluster_arrive(unsigned* ctr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool cluster_wait(unsigned* ctr, const unsigned target, unsigned* status, int* okw) {
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    int spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > BC_SPIN_LIMIT || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    *okw = ok;
+  }
+  __syncthreads();
+  return *okw != 0;
+}
+
+// sum over the 64 lanes of a wave (every lane gets the total)
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+
+// HM = H / 64.  One layer.
+template <int HM>
+__global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int H = 64 * HM, KG = H / 16, C = KG, UPW = H / 128 > 0 ? H / 128 : 1, KG3 = 3 * H / 16;
+  static_assert(H % 128 == 0, "hidden size is a multiple of 128");
+  const int W = a.W, D = a.D, V = a.V, B = a.B, G = a.G, N = a.N, NX = a.NX, NXT = a.NXT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = lane & 15, q = lane >> 4;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int gsub = slot / C, cu = slot - gsub * C;
+  const int g = gsub * 8 + xcd;
+  if (g >= G) return;
+  const int row0 = g * PMG_ROWS;
+  const int NOWN = (16 + C - 1) / C;
+  const int DW = D * W;
+  const bool owner = cu < 16;
+
+  // ---- LDS
+  float* wt_hh = reinterpret_cast<float*>(smem);     // [KG3][64][4]   rows 16cu.. of W_hh^T (reduction in chunk order)
+  float* wt_is = wt_hh + KG3 * 256;                  // [4][3][64][4]  own gate rows' part of W_ih[:, E:]^T
+  float* wt_x = wt_is + 12 * 256;                    // [NXT][64][4]   rows 16cu.. of [ctrl; push; out]^T
+  float* red = wt_x + (size_t)NXT * 256;             // [8][256] K-split partials; owners: [C][64] dtop partials
+  float* dgl = red + 8 * 256;                        // [4][256] own dr | dz | dn | dghn, D layout
+  float* dtl = dgl + 4 * 256;                        // [64] dtop of the sequence being served
+  float* dxl = dtl + 64;                             // [256] dx of the sequence being served
+  float* r3 = dxl + 256;                             // [8][4] control-gradient partials per wave
+  float* sprev = r3 + 32;                            // [D*W] S_{p-1} of the sequence being served
+  float* dsb = sprev + DW;                           // [NOWN][2][D*W] stack gradient ping-pong
+  int* misc = reinterpret_cast<int*>(dsb + (size_t)NOWN * 2 * DW);
+
+  // ---- exchange buffers of this cluster (floats): dg blocks [2][3][C][256] | partial dtop [C][4][256] |
+  //      dx records [16][256] | loss records [16][64]
+  const size_t o_dg = 0, o_pt = (size_t)2 * 3 * C * 256, o_dx = o_pt + (size_t)C * 4 * 256, o_ls = o_dx + 16 * 256;
+  const size_t cxs = o_ls + 16 * 64;
+  float* cx = a.CX + (size_t)g * cxs;
+  const __amdgpu_buffer_rsrc_t dgb0 = pmg_rsrc(cx + o_dg, (unsigned)(3 * C * 256) * 4u);
+  const __amdgpu_buffer_rsrc_t dgb1 = pmg_rsrc(cx + o_dg + (size_t)3 * C * 256, (unsigned)(3 * C * 256) * 4u);
+  const __amdgpu_buffer_rsrc_t ptb = pmg_rsrc(cx + o_pt, (unsigned)(C * 4 * 256) * 4u);
+  const __amdgpu_buffer_rsrc_t dxb = pmg_rsrc(cx + o_dx, 16u * 1024u);
+  const __amdgpu_buffer_rsrc_t lsb = pmg_rsrc(cx + o_ls, 16u * 256u);
+  unsigned* ctr = a.CXS + 32 + (size_t)g * 32;
+  unsigned* status = a.CXS;
+  unsigned bars = 0;
+#define BC_ARRIVE() (++bars, cluster_arrive(ctr))
+#define BC_WAIT() cluster_wait(ctr, (unsigned)C * bars, status, misc)
+
+  // ---- resident transposed weights out of the packs
+  {
+    const float* src = a.wbase + a.oWHHt[0] / 4 + (size_t)cu * KG3 * 256;
+    for (int i = tid * 4; i < KG3 * 256; i += BC_THREADS * 4) st4(wt_hh + i, ld4(src + i));
+    // W_ih[:, E:]^T: tile t (16 stack columns), reduction group of (piece, unit tile cu) in chunk order
+    const int kc = cu % UPW, kwv = cu / UPW;
+    for (int i = tid * 4; i < 12 * 256; i += BC_THREADS * 4) {
+      const int blk = i >> 8, t = blk / 3, piece = blk - 3 * t;
+      const int kgi = kc * 24 + piece * 8 + kwv;
+      st4(wt_is + i, ld4(a.wbase + a.oWIHt[0] / 4 + ((size_t)t * KG3 + kgi) * 256 + (i & 255)));
+    }
+    const float* srcx = a.wbase + a.oWXt / 4 + (size_t)cu * NXT * 256;
+    for (int i = tid * 4; i < NXT * 256; i += BC_THREADS * 4) st4(wt_x + i, ld4(srcx + i));
+  }
+  for (int i = tid; i < NOWN * 2 * DW; i += BC_THREADS) dsb[i] = 0.0f;
+  for (int i = tid; i < 256; i += BC_THREADS) dxl[i] = 0.0f;
+  if (tid < 64) misc[tid] = 0;
+  __syncthreads();
+
+  // stack thread mapping: thread -> (row offset sd0, column sw), rows sd0 + j*SDS (at most 8 per thread)
+  const int SDS = BC_THREADS / W;
+  const int sd0 = tid / W, sw = (sd0 < SDS) ? tid - sd0 * W : W;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 car = z4;                       // wave 0: hidden-state gradient of the own units (D layout)
+  f32x4 dhz = z4;                       // wave 0: z * dh of this step
+  float lossacc0 = 0.f, lossacc1 = 0.f; // thread 0: sum_p R * logp of each owned row
+  const float R0 = (owner && row0 + cu < B) ? a.reward[row0 + cu] : 0.0f;
+  const float R1 = (owner && NOWN > 1 && cu + C < 16 && row0 + cu + C < B) ? a.reward[row0 + cu + C] : 0.0f;
+  bool ok = true;
+
+  for (int p = N; p >= 0 && ok; --p) {
+    const bool virt = (p == N);
+    const __amdgpu_buffer_rsrc_t dgw = (p & 1) ? dgb1 : dgb0;
+    // ================================================================ members: cell backward of the own units
+    f32x4 gr = z4, gz = z4, gn = z4, gg = z4;      // wave 0: dr_pre, dz_pre, dn_pre, dghn
+    if (!virt) {
+      if (wave == 0) {
+        const float* gp = a.GT[0] + (((size_t)p * G + g) * KG + cu) * 1024 + lane * 4;
+        const f32x4 r = ld4(gp), z = ld4(gp + 256), n = ld4(gp + 512), ghn = ld4(gp + 768);
+        const float* hh = a.HH[0] + (((size_t)p * G + g) * H + 16 * cu + 4 * q) * 16 + b;
+        f32x4 hp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hp[j] = hh[j * 16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = car[j];
+          const float dn = d * (1.0f - z[j]);
+          const float dz = d * (hp[j] - n[j]);
+          gn[j] = dn * (1.0f - n[j] * n[j]);
+          const float dr = gn[j] * ghn[j];
+          gg[j] = gn[j] * r[j];
+          gz[j] = dz * z[j] * (1.0f - z[j]);
+          gr[j] = dr * r[j] * (1.0f - r[j]);
+          dhz[j] = d * z[j];
+        }
+        st4(dgl + lane * 4, gr); st4(dgl + 256 + lane * 4, gz); st4(dgl + 512 + lane * 4, gn); st4(dgl + 768 + lane * 4, gg);
+      }
+      __syncthreads();
+      if (wave < 4) {
+        // partial dtop of stack columns 16*wave..: the own 48 gate rows' share, B operand = own dgi blocks
+        f32x4 acc = z4;
+#pragma unroll
+        for (int piece = 0; piece < 3; ++piece) {
+          const f32x4 wv = ld4(wt_is + (size_t)(wave * 3 + piece) * 256 + lane * 4), x = ld4(dgl + piece * 256 + lane * 4);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], x[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], x[1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], x[2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], x[3], acc, 0, 0, 0);
+        }
+        xst4(ptb, (unsigned)((cu * 4 + wave) * 256 + lane * 4) * 4u, acc);
+      } else if (wave < 7) {
+        // dr | dz | dghn blocks of the own units for the other members' W_hh^T products
+        const int p3 = wave - 4;
+        xst4(dgw, (unsigned)((p3 * C + cu) * 256 + lane * 4) * 4u, ld4(dgl + (p3 == 2 ? 3 : p3) * 256 + lane * 4));
+      }
+      BC_ARRIVE();
+      if (wave == 0) {
+        // gate-gradient slab rows of the own units (A operand of the weight-gradient GEMM): off the chain
+        float* dg = a.DG[0] + (((size_t)p * G + g) * 4 * H + 16 * cu + 4 * q) * 16 + b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dg[(size_t)j * 16] = gr[j];
+          dg[((size_t)H + j) * 16] = gz[j];
+          dg[((size_t)2 * H + j) * 16] = gn[j];
+          dg[((size_t)3 * H + j) * 16] = gg[j];
+        }
+      }
+      if (!(ok = BC_WAIT())) break;              // A: every member's dgate blocks and dtop partials visible
+    }
+
+    // ================================================================ owners: per-sequence backward
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int s = cu + k * C;
+      if (k >= NOWN || s >= 16) break;
+      const int row = row0 + s;
+      const bool rowok = row < B;
+      const float Rs = k ? R1 : R0;
+      float* dsin = dsb + ((size_t)k * 2 + ((p + 1) & 1)) * DW;   // gradient w.r.t. S_p
+      float* dsout = dsb + ((size_t)k * 2 + (p & 1)) * DW;        // gradient w.r.t. S_{p-1}
+      // dlogits_{p-1} inputs and the old stack are requested first (plain loads: forward history)
+      float prv = 0.0f;
+      int y = 0;
+      if (p >= 1) {
+        y = rowok ? min(max((int)a.tokens[(size_t)p * B + row], 0), V - 1) : 0;
+        if (tid < V) prv = a.PR[(((size_t)(p - 1) * G + g) * a.VP + tid) * 16 + s];
+      }
+      if (!virt) {
+        // S_{p-1}: rows <= min(p-1, N-p, D-1) hold data (pmg_fwd.hip "live rows"), the rest is zero
+        const int s_hi = (p == 0) ? -1 : min(min(p - 1, N - p), D - 1);
+        const float* Sp = a.SB + ((size_t)p * G + g) * a.SW;
+        for (int d = sd0; d < D; d += SDS)
+          if (sw < W) sprev[d * W + sw] = (d <= s_hi) ? Sp[(size_t)(d * W + sw) * 16 + s] : 0.0f;
+        // dtop of this sequence: sum of the C members' partials
+        for (int t = tid; t < C * 16; t += BC_THREADS) {
+          const int cm = t >> 4, tt = (t >> 2) & 3, kq = t & 3;
+          st4(red + cm * 64 + 16 * tt + 4 * kq, xld4(ptb, (unsigned)((cm * 4 + tt) * 256 + (s + 16 * kq) * 4) * 4u));
+        }
+        __syncthreads();
+        if (tid < 64) {
+          float acc = 0.0f;
+          for (int cm = 0; cm < C; ++cm) acc += red[cm * 64 + tid];
+          dtl[tid] = acc;
+        }
+        const float apush = a.CT[((size_t)p * G + g) * 64 + s], apop = a.CT[((size_t)p * G + g) * 64 + 16 + s],
+                    anoop = a.CT[((size_t)p * G + g) * 64 + 32 + s];
+        __syncthreads();
+        // ---- stack backward: G(d) = dS_p[d] (+ dtop at row 0); rows beyond N-p carry no gradient
+        const int dlim = min(N - p, D - 1);
+        float sn = 0.0f, sp = 0.0f, sq = 0.0f;
+        if (sw < W) {
+          const float pv = a.PV[((size_t)p * G + g) * 1024 + sw * 16 + s];
+          const float dt = dtl[sw];
+          for (int d = sd0; d <= dlim; d += SDS) {
+            const int idx = d * W + sw;
+            const float gc = dsin[idx] + (d == 0 ? dt : 0.0f);
+            const float gm = (d == 0) ? 0.0f : dsin[idx - W] + (d == 1 ? dt : 0.0f);
+            const float gx = (d + 1 < D) ? dsin[idx + W] : 0.0f;
+            const float sc = sprev[idx];
+            const float su = (d == 0) ? pv : sprev[idx - W];
+            const float sdn = (d + 1 < D) ? sprev[idx + W] : 0.0f;
+            sn += gc * sc; sp += gc * su; sq += gc * sdn;
+            dsout[idx] = anoop * gc + apush * gx + apop * gm;
+            if (d == 0) dxl[3 + sw] = apush * gc * (1.0f - pv * pv);
+          }
+        }
+        sn = wave_sum(sn); sp = wave_sum(sp); sq = wave_sum(sq);
+        if (lane == 0) { r3[wave * 4] = sp; r3[wave * 4 + 1] = sq; r3[wave * 4 + 2] = sn; }
+        __syncthreads();
+        if (tid == 0) {
+          float dpu = 0.f, dpo = 0.f, dno = 0.f;
+          for (int wv = 0; wv < 8; ++wv) { dpu += r3[wv * 4]; dpo += r3[wv * 4 + 1]; dno += r3[wv * 4 + 2]; }
+          const float sm = apush * dpu + apop * dpo + anoop * dno;
+          dxl[0] = apush * (dpu - sm); dxl[1] = apop * (dpo - sm); dxl[2] = anoop * (dno - sm);
+        }
+      } else {
+        if (tid < 3 + W) dxl[tid] = 0.0f;
+      }
+      // ---- dlogits_{p-1} and the loss term
+      if (tid < V) dxl[3 + W + tid] = (p >= 1) ? a.scale * Rs * (prv - ((tid == y) ? 1.0f : 0.0f)) : 0.0f;
+      if (tid == 0 && p >= 1) {
+        const float lp = a.LP[((size_t)(p - 1) * G + g) * 16 + s];
+        if (k) lossacc1 += Rs * lp; else lossacc0 += Rs * lp;
+      }
+      __syncthreads();
+      // ---- publish dx of this sequence (1-KB record: one 16-byte store per lane of wave 0) and its DX slab column
+      if (wave == 0) xst4(dxb, (unsigned)(s * 256 + lane * 4) * 4u, ld4(dxl + lane * 4));
+      if (tid < NXT * 16) a.DX[((size_t)p * G + g) * NXT * 256 + (size_t)tid * 16 + s] = dxl[tid];
+      if (k + 1 < NOWN) __syncthreads();
+    }
+    BC_ARRIVE();
+    // ---- under the wait of barrier B: W_hh^T [dr; dz; dghn] for the own units, K split over the waves
+    if (!virt) {
+      f32x4 acc0 = z4, acc1 = z4;
+      constexpr int KPW = KG3 / 8;
+#pragma unroll
+      for (int i = 0; i < KPW; ++i) {
+        const int kgi = wave * KPW + i;
+        const int kc = kgi / 24, rem = kgi - kc * 24, piece = rem >> 3, kwv = rem & 7;
+        const int u = kwv * UPW + kc;
+        const f32x4 x = xld4(dgw, (unsigned)((piece * C + u) * 256 + lane * 4) * 4u);
+        const f32x4 wv = ld4(wt_hh + (size_t)kgi * 256 + lane * 4);
+        if (i & 1) {
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], x[0], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], x[1], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], x[2], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], x[3], acc1, 0, 0, 0);
+        } else {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], x[0], acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], x[1], acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], x[2], acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], x[3], acc0, 0, 0, 0);
+        }
+      }
+      st4(red + wave * 256 + lane * 4, acc0 + acc1);
+    }
+    if (!(ok = BC_WAIT())) break;                // B: dx of all 16 sequences visible
+    // ================================================================ members: the new carry of the own units
+    if (wave == 0) {
+      f32x4 acc0 = virt ? z4 : dhz, acc1 = z4;
+      if (!virt) {
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) acc1 += ld4(red + wv * 256 + lane * 4);
+      }
+      for (int kg = 0; kg < NXT; ++kg) {
+        const f32x4 x = xld4(dxb, (unsigned)(b * 256 + 16 * kg + 4 * q) * 4u);
+        const f32x4 wv = ld4(wt_x + (size_t)kg * 256 + lane * 4);
+        if (kg & 1) {
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], x[0], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], x[1], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], x[2], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], x[3], acc1, 0, 0, 0);
+        } else {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], x[0], acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], x[1], acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], x[2], acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], x[3], acc0, 0, 0, 0);
+        }
+      }
+      car = acc0 + acc1;
+    }
+    __syncthreads();                             // red / dxl reusable
+  }
+
+  // ---------------------------------------------------------------- outputs
+  if (!ok) {
+    // gave up on a barrier: poison what the caller will look at
+    const float nanv = __int_as_float(0x7fc00000);
+    if (wave == 0 && row0 + b < B) st4(a.grad_h0 + (size_t)(row0 + b) * H + 16 * cu + 4 * q, (f32x4){nanv, nanv, nanv, nanv});
+    if (cu == 0 && tid == 0) a.LOSSP[g] = nanv;
+    return;
+  }
+  if (wave == 0 && row0 + b < B) st4(a.grad_h0 + (size_t)(row0 + b) * H + 16 * cu + 4 * q, car);
+  // loss partial of the row group: owners publish sum_p R * logp of their rows, member 0 adds them in row order
+  if (owner && wave == 0) {
+    xst1(lsb, (unsigned)(cu * 64 + lane) * 4u, lane == 0 ? lossacc0 : 0.0f);
+    if (NOWN > 1 && cu + C < 16) xst1(lsb, (unsigned)((cu + C) * 64 + lane) * 4u, lane == 0 ? lossacc1 : 0.0f);
+  }
+  BC_ARRIVE();
+  ok = BC_WAIT();
+  if (cu == 0 && tid == 0) {
+    float sacc = 0.0f;
+    for (int r = 0; r < 16; ++r) sacc += xld1(lsb, (unsigned)(r * 64) * 4u);
+    a.LOSSP[g] = ok ? -a.scale * sacc : __int_as_float(0x7fc00000);
+  }
+}
+
+size_t bwdc_lds_bytes(const BwdArgs* a) {
+  const int KG = a->H / 16, nown = (16 + KG - 1) / KG, KG3 = 3 * a->H / 16;
+  return ((size_t)KG3 * 256 + 12 * 256 + (size_t)a->NXT * 256 + 8 * 256 + 4 * 256 + 64 + 256 + 32 + (size_t)a->D * a->W +
+          (size_t)nown * 2 * a->D * a->W + 64) * sizeof(float);
+}
+
+}  // namespace
+
+// Floats of the exchange region per launch (G clusters).
+size_t pmg_bwdc_cx_floats(const PmgDims& d) {
+  const size_t C = d.H / 16;
+  return (size_t)d.G * ((size_t)2 * 3 * C * 256 + C * 4 * 256 + 16 * 256 + 16 * 64);
+}
+
+bool pmg_bwdc_applicable(const BwdArgs* a) {
+  if (a->flags & PMG_FLAG_NO_CLUSTER) return false;
+  if (a->L != 1 || a->H > 512 || a->NX > 256 || a->V > 512 || a->CX == nullptr) return false;
+  const int C = a->H / 16;
+  if (a->G > 8 * (32 / C)) return false;
+  if (BC_THREADS / a->W < 1) return false;
+  return bwdc_lds_bytes(a) <= (size_t)160 * 1024;
+}
+
+hipError_t pmg_launch_bwdc(const BwdArgs* a, hipStream_t st) {
+  const int C = a->H / 16;
+  size_t lds = bwdc_lds_bytes(a);
+  if (lds < (size_t)81 * 1024) lds = (size_t)81 * 1024;     // more than half a CU: one workgroup per CU
+  hipError_t e = hipMemsetAsync(a->CXS, 0, (size_t)32 * (1 + a->G) * sizeof(unsigned), st);
+  if (e != hipSuccess) return e;
+  const int grid = 8 * C * ((a->G + 7) / 8);
+#define BC_LAUNCH(HM_)                                                                                  \
+  {                                                                                                     \
+    static std::atomic<unsigned long long> done{0};                                                     \
+    e = pmg_full_lds_once(reinterpret_cast<const void*>(pmg_bwdc_kernel<HM_>), &done);                  \
+    if (e != hipSuccess) return e;                                                                      \
+    hipLaunchKernelGGL((pmg_bwdc_kernel<HM_>), dim3(grid), dim3(BC_THREADS), lds, st, *a);              \
+    return hipGetLastError();                                                                           \
+  }
+  switch (a->H) {
+    case 128: BC_LAUNCH(2)
+    case 256: BC_LAUNCH(4)
+    case 384: BC_LAUNCH(6)
+    case 512: BC_LAUNCH(8)
+  }
+#undef BC_LAUNCH
+  return hipErrorInvalidValue;
+}

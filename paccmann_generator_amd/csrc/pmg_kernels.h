@@ -128,8 +128,14 @@ struct BwdArgs {
   float* DHC;                 // [G][L][UT][64][4] hidden-gradient carry (D layout)
   float* grad_h0;             // [L][B][H]
   float* LOSSP;               // [G] loss partials
+  // clustered BPTT (pmg_bwdc.hip): exchange buffers, counters, caller's flags
+  float* CX; unsigned* CXS; uint32_t flags;
 };
 
 hipError_t pmg_launch_bwd(const BwdArgs* a, hipStream_t st);
 size_t pmg_bwd_lds_bytes(const BwdArgs* a);
 int pmg_bwd_chunk_buffers(const BwdArgs* a);
+// clustered BPTT for small batches (pmg_bwdc.hip); pmg_launch_bwd picks it by shape
+bool pmg_bwdc_applicable(const BwdArgs* a);
+hipError_t pmg_launch_bwdc(const BwdArgs* a, hipStream_t st);
+size_t pmg_bwdc_cx_floats(const PmgDims& d);

@@ -311,8 +311,8 @@ def _reinforce_bwd_op(tokens: Tensor, reward: Tensor, scale: float, ws: Tensor, 
     grad_h0 = torch.empty(d['L'], B, d['H'], dtype=torch.float32, device=tokens.device)
     loss = torch.empty(1, dtype=torch.float32, device=tokens.device)
     rc = _ffi.lib.pmg_reinforce_bwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(tokens), _ffi._ptr(reward),
-                                    float(scale), 0, C.byref(gstruct), _ffi._ptr(grad_h0), _ffi._ptr(loss),
-                                    _ffi._ptr(ws), _ffi.current_stream())
+                                    float(scale), _cluster_flag(), C.byref(gstruct), _ffi._ptr(grad_h0),
+                                    _ffi._ptr(loss), _ffi._ptr(ws), _ffi.current_stream())
     _ffi.check(rc, 'pmg_reinforce_bwd')
     del keep, keep2
     return loss, grad_h0, grads
@@ -396,7 +396,8 @@ def _reinforce_loss_op(tokens: Tensor, h0: Tensor, reward: Tensor, scale: float,
             r_c = reward if whole else reward[lo:hi].contiguous()
             gh_c = grad_h0 if whole else torch.empty(L, hi - lo, H, dtype=torch.float32, device=dev)
             rc = _ffi.lib.pmg_reinforce_bwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(tok_c), _ffi._ptr(r_c),
-                                            float(scale), _ffi.PMG_FLAG_ACCUMULATE if i > 0 else 0,
+                                            float(scale),
+                                            (_ffi.PMG_FLAG_ACCUMULATE if i > 0 else 0) | _cluster_flag(),
                                             C.byref(gstruct), _ffi._ptr(gh_c), _ffi._ptr(loss), _ffi._ptr(ws), st)
             _ffi.check(rc, 'pmg_reinforce_bwd')
             if not whole:
@@ -475,7 +476,8 @@ class TrainSlice:
         self.grad_h0 = torch.empty(d['L'], B, d['H'], dtype=torch.float32, device=dev)
         self.loss = torch.empty(1, dtype=torch.float32, device=dev)
         rc = _ffi.lib.pmg_reinforce_bwd(C.byref(self.shape), C.byref(self.wstruct), _ffi._ptr(self.tokens),
-                                        _ffi._ptr(self.reward), float(scale), 0, C.byref(gstruct),
+                                        _ffi._ptr(self.reward), float(scale), _ffi.PMG_FLAG_NO_CLUSTER,
+                                        C.byref(gstruct),
                                         _ffi._ptr(self.grad_h0), _ffi._ptr(self.loss), _ffi._ptr(self.ws),
                                         _ffi.current_stream())
         _ffi.check(rc, 'pmg_reinforce_bwd')

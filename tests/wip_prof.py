@@ -34,7 +34,7 @@ st = _ffi.current_stream()
 def fwd():
     _ffi.check(_ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(h0), _ffi._ptr(logp), None, 0, _ffi._ptr(ws), st), 'fwd')
 def bptt():
-    _ffi.check(_ffi.lib.pmg_reinforce_bptt(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(rewards), 1.0 / B, _ffi._ptr(gh0), _ffi._ptr(ws), st), 'bptt')
+    _ffi.check(_ffi.lib.pmg_reinforce_bptt(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), _ffi._ptr(rewards), 1.0 / B, 0, _ffi._ptr(gh0), _ffi._ptr(ws), st), 'bptt')
 def wgrad():
     _ffi.check(_ffi.lib.pmg_reinforce_wgrad(C.byref(shape), C.byref(wstruct), _ffi._ptr(padded), 0, C.byref(gstruct), _ffi._ptr(loss), _ffi._ptr(ws), st), 'wgrad')
 fwd(); bptt(); torch.cuda.synchronize()
