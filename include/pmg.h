@@ -99,8 +99,9 @@ const char* pmg_strerror(int code);
  * layers may not) -- else the error code every entry point would return for it. */
 int pmg_check_shape(const pmg_shape* s, int mode);
 
-/* 1 if pmg_decode (mode PMG_MODE_DECODE) / pmg_logprob_fwd (PMG_MODE_TRAIN) would take the
- * clustered small-batch kernels for shape `s` with these flags, 0 if the batch-partitioned ones,
+/* Which launches would take the clustered small-batch kernels for shape `s` with these flags:
+ * PMG_MODE_DECODE: 1 if pmg_decode does; PMG_MODE_TRAIN: bit 0 for pmg_logprob_fwd, bit 1 for
+ * pmg_reinforce_bptt (the recurrent half of pmg_reinforce_bwd); 0 = the batch-partitioned kernels,
  * negative for an unsupported shape.  Clustered: one layer, H <= 512, B <= 16 * 8 * floor(512 / H)
  * sequences, 3+W+V <= 256; a cluster of H/16 workgroups (one per CU) serves 16 sequences and
  * synchronises through device memory twice per time step, so every cluster member must be resident

@@ -230,7 +230,16 @@ extern "C" int pmg_uses_cluster(const pmg_shape* s, int mode, uint32_t flags) {
   fill_fwd_common(&a, d, lay, reinterpret_cast<float*>(256));   // addresses are only compared with null
   a.mode = (mode == PMG_MODE_DECODE) ? PMG_FWD_DECODE : PMG_FWD_TEACHER;
   a.flags = flags;
-  return pmg_fwdc_applicable(&a) ? 1 : 0;
+  int r = pmg_fwdc_applicable(&a) ? 1 : 0;
+  if (mode == PMG_MODE_TRAIN) {
+    BwdArgs b;
+    memset(&b, 0, sizeof(b));
+    b.B = d.B; b.G = d.G; b.N = d.T - 1; b.H = d.H; b.W = d.W; b.D = d.D; b.V = d.V; b.L = d.L;
+    b.NX = d.NX; b.NXT = d.NXT; b.flags = flags;
+    b.CX = lay.CXS ? reinterpret_cast<float*>(256) : nullptr;
+    if (pmg_bwdc_applicable(&b)) r |= 2;
+  }
+  return r;
 }
 
 static void fill_extras(FwdArgs* a, const pmg_weights* w) {

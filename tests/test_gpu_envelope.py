@@ -40,6 +40,18 @@ def test_vocabularies_of_a_few_hundred_tokens(gpu, V, H):
     P.check_step(cfg, 17)
 
 
+@pytest.mark.parametrize('H,V,W,D,B,T', [
+    (256, 180, 20, 12, 33, 40),     # 3+W+V in (128, 256]: the 1-KB dx records of the clustered BPTT; a cluster with one row
+    (128, 40, 64, 2, 70, 25),       # widest stack, shallowest: 8 stack rows per pass of the 512 threads, 2 sequences per owner
+    (512, 60, 50, 50, 128, 70),     # the largest clustered launch at hidden 512 (8 clusters of 32 CUs), T past the depth
+    (384, 97, 33, 7, 96, 19),       # 24 CUs per cluster, odd sizes everywhere
+])
+def test_small_batch_cluster_edges(gpu, H, V, W, D, B, T):
+    cfg = dict(MID, rnn_cell_size=H, vocab_size=V, stack_width=W, stack_depth=D)
+    P.check_train(cfg, B=B, T=T, tol=TOL)
+    assert P.check_greedy(cfg, B, T)['mismatched_rows'] == 0
+
+
 def test_wide_vocabulary_with_the_reference_stack_and_hidden_768(gpu):
     cfg = dict(P.CFG1, rnn_cell_size=768, vocab_size=575)
     P.check_train(cfg, B=17, T=20, tol=TOL)
