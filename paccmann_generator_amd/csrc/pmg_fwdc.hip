@@ -104,49 +104,93 @@ __device__ __forceinline__ bool cluster_wait(unsigned* ctr, const unsigned targe
   return *okw != 0;
 }
 
+// LDS map (float offsets), shared by the kernel and the host-side size check.  NG = row groups per
+// cluster, NOWN = sequences a member may own, DW = stack floats per sequence.
+struct FcLds { unsigned red, wlz, bxl, xexs, hls, hl, ghl, stk, ptv, osm, misc, gtl; };
+// the z tile of the own units stays in LDS at hidden 512 (registers: r and n tiles only)
+__host__ __device__ constexpr bool fc_zreg(const int H) { return H < 512; }
+__host__ __device__ inline FcLds fc_lds(const int H, const int NG, const int NOWN, const int DW) {
+  FcLds o;
+  unsigned p = 0;
+  o.red = p; p += 2 * 8 * 2 * 256;          // [2][8 waves][2][256] K-split partials, double-buffered over the groups
+  o.wlz = p; p += fc_zreg(H) ? 0u : (unsigned)(H / 16) * 256u;   // [KG][64][4] z tile (hidden 512 only)
+  o.bxl = p; p += 256;                      // [256] extras bias (ctrl | push | out)
+  o.xexs = p; p += (unsigned)NOWN * 256;    // [NOWN][256] extras of the owned sequences
+  o.hls = p; p += (unsigned)NOWN * H;       // [NOWN][H] hidden states of the owned sequences
+  o.hl = p; p += (unsigned)NG * 256;        // [NG][64][4] own units of the current hidden state (D layout, wave 0)
+  o.ghl = p; p += 4 * 256;                  // [4][64][4] r | z | n | W_hn h of the last group (history, deferred; wave 0)
+  o.stk = p; p += (unsigned)NOWN * 2 * DW;  // [NOWN][2][D*W] own sequences' stacks (ping-pong)
+  o.ptv = p; p += (unsigned)NOWN * 128;     // [NOWN][2][64] push value | new stack top (history, deferred)
+  o.osm = p; p += (unsigned)NOWN * 8;       // [NOWN][8] push, pop, no-op | uniform | token, finished, length
+  o.misc = p; p += 64;                      // [0] barrier ok, [1..] scratch
+  o.gtl = (p + 3u) & ~3u;                   // [V][3][16] token-table lines of the own units (if they fit)
+  return o;
+}
+
 // MODE: PMG_FWD_DECODE or PMG_FWD_TEACHER.  One layer.  HM = H / 64: float4 per lane and extras row.
+//
+// A cluster serves NG consecutive row groups (NG = 1 while there are at least as many clusters as row
+// groups; above that each step's two barriers are shared by NG groups): sequence sigma = 16 r + s of
+// the cluster (group r, row s) is OWNED by member sigma % C, so a member owns up to NOWN sequences and
+// runs their per-sequence work one after the other; the gates of the own units are formed group by group.
+// The gate rows of the own units live in REGISTERS (each wave keeps the K quarter of the gate tiles
+// it multiplies; at hidden 512 the z tile stays in LDS), so the LDS is left to the owned sequences' stacks.
 template <int MODE, int HM>
 __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool teacher = (MODE == PMG_FWD_TEACHER);
   constexpr bool decode = (MODE == PMG_FWD_DECODE);
-  constexpr int H = 64 * HM, KG = H / 16, C = KG;
-  const int W = a.W, D = a.D, V = a.V, B = a.B, G = a.G, N = a.N, NX = a.NX;                 // members per cluster = unit tiles
+  constexpr int H = 64 * HM, KG = H / 16, C = KG;   // members per cluster = unit tiles
+  const int W = a.W, D = a.D, V = a.V, B = a.B, G = a.G, N = a.N, NX = a.NX;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = lane & 15, q = lane >> 4;
   // workgroup -> (cluster, member): clusters are dealt over the XCDs first
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int gsub = slot / C, cu = slot - gsub * C;
-  const int g = gsub * 8 + xcd;
-  if (g >= G) return;                            // a whole cluster absent: nobody waits for it
-  const int row0 = g * PMG_ROWS;
-  const int NOWN = (16 + C - 1) / C;             // sequences this member may own: s = cu + k*C
+  const int csub = slot / C, cu = slot - csub * C;
+  const int cl = csub * 8 + xcd;
+  const int NG = a.cluster_ng;
+  const int g0 = cl * NG;                        // first row group of this cluster
+  if (g0 >= G) return;                           // a whole cluster absent: nobody waits for it
+  const int NGc = (G - g0 < NG) ? G - g0 : NG;   // row groups of this cluster
+  const int NS = 16 * NGc;                       // its sequences: sigma = 16 r + s, global row = 16 g0 + sigma
+  const int NOWN = (16 * NG + C - 1) / C;        // owned sequences the LDS is laid out for
+  const int nown = (cu < NS) ? (NS - cu + C - 1) / C : 0;   // owned by this member: sigma = cu + k C
+  const int row00 = g0 * PMG_ROWS;
   const int DW = D * W;
 
   // ---- LDS
-  float* wl_hh = reinterpret_cast<float*>(smem);            // [3][KG][64][4] packed gate rows of the own units
-  float* wl_is = wl_hh + 3 * KG * 256;                      // [3][4][64][4]  stack-top columns of W_ih
-  float* red = wl_is + 3 * 4 * 256;                         // [8 waves][2][256] K-split partials
-  float* bxl = red + 8 * 2 * 256;                           // [256] extras bias (ctrl | push | out)
-  float* xex = bxl + 256;                                   // [256] extras of the sequence being served
-  float* stk = xex + 256;                                   // [NOWN][2][D*W] own sequences' stacks (ping-pong)
-  int* misc = reinterpret_cast<int*>(stk + (size_t)NOWN * 2 * DW);   // [0] barrier ok, [1..] scratch
-  float* gtl = reinterpret_cast<float*>(misc + 64);         // [V][3][16] token-table lines of the own units (if they fit)
+  constexpr bool ZREG = fc_zreg(H);
+  const FcLds lo = fc_lds(H, NG, NOWN, DW);
+  float* fs = reinterpret_cast<float*>(smem);
+  float* red = fs + lo.red;
+  float* wlz = fs + lo.wlz;
+  float* bxl = fs + lo.bxl;
+  float* xexs = fs + lo.xexs;
+  float* hls = fs + lo.hls;
+  float* hl = fs + lo.hl;
+  float* ghl = fs + lo.ghl;
+  float* stk = fs + lo.stk;
+  float* ptv = fs + lo.ptv;
+  float* osm = fs + lo.osm;
+  int* osi = reinterpret_cast<int*>(osm);
+  int* misc = reinterpret_cast<int*>(fs + lo.misc);
+  float* gtl = fs + lo.gtl;
   const bool gt_lds = a.cluster_gtab_lds != 0;
 
-  // ---- exchange buffers of this cluster
-  const size_t cxs = (size_t)2 * H * 16 + 16 * 128;         // floats per cluster
-  float* cx = a.CX + (size_t)g * cxs;
-  const __amdgpu_buffer_rsrc_t hb0 = pmg_rsrc(cx, (unsigned)H * 64u), hb1 = pmg_rsrc(cx + (size_t)H * 16, (unsigned)H * 64u);
-  const __amdgpu_buffer_rsrc_t rec = pmg_rsrc(cx + (size_t)2 * H * 16, 16u * 512u);   // [16][128]: top[64] | token, finished
-  unsigned* ctr = a.CXS + 32 + (size_t)g * 32;              // counter of this cluster (own 128-B line)
+  // ---- exchange buffers of this cluster: two hidden-state buffers [NG][KG][64][4], records [16 NG][128]
+  const size_t hbf = (size_t)NG * H * 16;
+  const size_t cxs = 2 * hbf + (size_t)NG * 16 * 128;       // floats per cluster
+  float* cx = a.CX + (size_t)cl * cxs;
+  const __amdgpu_buffer_rsrc_t hb0 = pmg_rsrc(cx, (unsigned)(hbf * 4)), hb1 = pmg_rsrc(cx + hbf, (unsigned)(hbf * 4));
+  const __amdgpu_buffer_rsrc_t rec = pmg_rsrc(cx + 2 * hbf, (unsigned)NG * 16u * 512u);   // per sequence: top[64] | token, finished
+  unsigned* ctr = a.CXS + 32 + (size_t)cl * 32;             // counter of this cluster (own 128-B line)
   unsigned* status = a.CXS;                                  // one word for the launch
   unsigned bars = 0;
 #define FC_ARRIVE() (++bars, cluster_arrive(ctr))
 #define FC_WAIT() cluster_wait(ctr, (unsigned)C * bars, status, misc)
 #ifdef PMG_PROFILE
   // -DPMG_PROFILE build + PMG_DEBUG bit 0x8000: per-phase cycle counters of member 0 of cluster 0
-  const bool prof = (a.dbg & 0x8000) != 0 && g == 0 && cu == 0;
+  const bool prof = (a.dbg & 0x8000) != 0 && cl == 0 && cu == 0;
   long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #define FC_TICK(k) if (prof) { const long long tn_ = (long long)__builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; }
@@ -154,15 +198,33 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
 #define FC_TICK(k)
 #endif
 
-  // ---- resident weights: the packed forward operands of pmg_pack.hip, tiles 3*cu .. 3*cu+2
+  // ---- resident weights (registers): the packed forward operands of pmg_pack.hip, tiles 3*cu .. 3*cu+2.
+  // K split: waves 0-3 carry the r and z tiles of K quarter kw, waves 4-7 the n tile.
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const int kw = wave & 3;
+  const int kq0 = kw * HM;                       // KG / 4 = HM reduction groups per wave
+  f32x4 wres[ZREG ? 2 * HM : HM], wis0, wis1;
   {
-    const float* src = a.wbase + a.oWHH[0] / 4 + (size_t)(3 * cu) * KG * 256;
-    for (int i = tid * 4; i < 3 * KG * 256; i += FC_THREADS * 4) st4(wl_hh + i, ld4(src + i));
-    const float* src2 = a.wbase + a.oWIH[0] / 4 + (size_t)(3 * cu) * 4 * 256;
-    for (int i = tid * 4; i < 3 * 4 * 256; i += FC_THREADS * 4) st4(wl_is + i, ld4(src2 + i));
+    const int ga = (wave < 4) ? 0 : 2;
+    const float* src = a.wbase + a.oWHH[0] / 4 + ((size_t)(3 * cu + ga) * KG + kq0) * 256 + lane * 4;
+    const float* srcz = a.wbase + a.oWHH[0] / 4 + ((size_t)(3 * cu + 1) * KG + kq0) * 256 + lane * 4;
+#pragma unroll
+    for (int m = 0; m < HM; ++m) {
+      wres[m] = ld4(src + (size_t)m * 256);
+      if constexpr (ZREG) wres[HM + m] = (wave < 4) ? ld4(srcz + (size_t)m * 256) : z4;
+    }
+    if constexpr (!ZREG) {
+      const float* sz = a.wbase + a.oWHH[0] / 4 + (size_t)(3 * cu + 1) * KG * 256;
+      for (int i = tid * 4; i < KG * 256; i += FC_THREADS * 4) st4(wlz + i, ld4(sz + i));
+    }
+    wis0 = ld4(a.wbase + a.oWIH[0] / 4 + ((size_t)(3 * cu + ga) * 4 + kw) * 256 + lane * 4);
+    wis1 = (wave < 4) ? ld4(a.wbase + a.oWIH[0] / 4 + ((size_t)(3 * cu + 1) * 4 + kw) * 256 + lane * 4) : z4;
   }
   for (int i = tid; i < NOWN * 2 * DW; i += FC_THREADS) stk[i] = 0.0f;
   if (tid < 64) misc[tid] = 0;
+  for (int i = tid; i < NOWN * 8; i += FC_THREADS) {
+    if ((i & 7) == 6) osi[i] = N; else osm[i] = 0.0f;        // length N, not finished
+  }
   if (gt_lds)
     for (int idx = tid; idx < V * 48; idx += FC_THREADS) {
       const int v = idx / 48, rem = idx - v * 48;
@@ -177,7 +239,6 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
   const int l16 = tid & 15, rgrp = tid >> 4;
   const int RX = (NX + 31) >> 5;                 // rows per 16-lane group
   const int NCH = (RX + RC - 1) / RC;            // chunks (1 at hidden <= 256 and NX <= 128)
-  const bool owner = cu < 16;
   f32x4 wreg[RC * HM];
   auto load_chunk = [&](const int c) {
 #pragma unroll
@@ -187,111 +248,113 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
                                 : (n < 3 + W) ? a.w_push + (size_t)(n - 3) * H : a.w_out + (size_t)(n - 3 - W) * H;
 #pragma unroll
       for (int m = 0; m < HM; ++m)
-        wreg[r * HM + m] = (n < NX) ? ld4(wr + 4 * l16 + 64 * m) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        wreg[r * HM + m] = (n < NX) ? ld4(wr + 4 * l16 + 64 * m) : z4;
     }
   };
 
-  // ---- h0 of the own units for the 16 sequences (D layout: lane (b, q) holds units 4q..4q+3 of row b)
-  f32x4 hown = {0.f, 0.f, 0.f, 0.f};             // wave 0 only: own slice of the current hidden state
+  // ---- h0 of the own units for the 16 sequences of every group (D layout: lane (b, q) holds units 4q..4q+3 of row b)
   if (wave == 0) {
-    const int row = row0 + b;
-    if (decode) {
-      // latent_to_hidden tile cu: packed [tile][Z/16][64][4] (PK_L2H), B operand straight from the latents
-      const float* wz = a.wbase + a.oL2H / 4 + (size_t)cu * (a.Z / 16) * 256 + lane * 4;
-      f32x4 acc = ld4(a.b_l2h + 16 * cu + 4 * q), acc2 = {0.f, 0.f, 0.f, 0.f};
-      for (int kg = 0; kg < a.Z / 16; kg += 2) {
-        const f32x4 w0 = ld4(wz + (size_t)kg * 256), w1 = ld4(wz + (size_t)(kg + 1) * 256);
-        f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
-        if (row < B) {
-          x0 = ld4(a.latent + (size_t)row * a.Z + 16 * kg + 4 * q);
-          x1 = ld4(a.latent + (size_t)row * a.Z + 16 * (kg + 1) + 4 * q);
-        }
+    for (int r = 0; r < NGc; ++r) {
+      const int row = row00 + 16 * r + b;
+      f32x4 hown = z4;
+      if (decode) {
+        // latent_to_hidden tile cu: packed [tile][Z/16][64][4] (PK_L2H), B operand straight from the latents
+        const float* wz = a.wbase + a.oL2H / 4 + (size_t)cu * (a.Z / 16) * 256 + lane * 4;
+        f32x4 acc = ld4(a.b_l2h + 16 * cu + 4 * q), acc2 = z4;
+        for (int kg = 0; kg < a.Z / 16; kg += 2) {
+          const f32x4 w0 = ld4(wz + (size_t)kg * 256), w1 = ld4(wz + (size_t)(kg + 1) * 256);
+          f32x4 x0 = z4, x1 = z4;
+          if (row < B) {
+            x0 = ld4(a.latent + (size_t)row * a.Z + 16 * kg + 4 * q);
+            x1 = ld4(a.latent + (size_t)row * a.Z + 16 * (kg + 1) + 4 * q);
+          }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[c], x0[c], acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[c], x1[c], acc2, 0, 0, 0);
+          for (int c = 0; c < 4; ++c) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[c], x0[c], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[c], x1[c], acc2, 0, 0, 0);
+          }
         }
+        hown = acc + acc2;
+      } else if (row < B) {
+        hown = ld4(a.h0 + (size_t)row * H + 16 * cu + 4 * q);
       }
-      hown = acc + acc2;
-    } else if (row < B) {
-      hown = ld4(a.h0 + (size_t)row * H + 16 * cu + 4 * q);
-    }
-    xst4(hb0, (unsigned)(cu * 256 + lane * 4) * 4u, hown);
-    if (teacher) {
+      st4(hl + r * 256 + lane * 4, hown);
+      xst4(hb0, (unsigned)((r * KG + cu) * 256 + lane * 4) * 4u, hown);
+      if (teacher) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) a.HH[0][((size_t)g * H + 16 * cu + 4 * q + j) * 16 + b] = hown[j];
+        for (int j = 0; j < 4; ++j) a.HH[0][((size_t)(g0 + r) * H + 16 * cu + 4 * q + j) * 16 + b] = hown[j];
+      }
     }
   }
   FC_ARRIVE();
-  if (owner) load_chunk(0);
+  if (nown > 0) load_chunk(0);
   bool ok = FC_WAIT();                            // h0 of every member visible
-  float u0 = 0.f, u1 = 0.f;                       // the uniform of the next draw of each owned row (decode)
-  float pv0 = 0.f, pv1 = 0.f, top0 = 0.f, top1 = 0.f;   // wave 0: push value / new stack top of each owned row (history, deferred)
-  float* fm = reinterpret_cast<float*>(misc + 16);      // [2][4] stack controls of the owned rows
   // deferred stack update: thread -> (row offset sd0, column sw), SDS rows apart (no division in the loop)
   const int SDS = FC_THREADS / W;                 // W <= 64: at least 8 rows in flight
   const int sd0 = tid / W, sw = (sd0 < SDS) ? tid - sd0 * W : W;
-
-  // per owned sequence (k < NOWN): sampling state, identical in the lanes that serve it
-  bool fin0 = false, fin1 = false;
-  int mylen0 = N, mylen1 = N;
-  const f32x4 bhn = (wave == 0) ? ld4(a.BG[0] + 3 * H + 16 * cu + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  const f32x4 bhn = (wave == 0) ? ld4(a.BG[0] + 3 * H + 16 * cu + 4 * q) : z4;
 
   FC_TICK(7)
-  f32x4 gr = {0.f, 0.f, 0.f, 0.f}, gz = gr, gn = gr, gvh = gr;    // wave 0, teacher: gates of this step (history)
   for (int i = 0; ok; ++i) {
     const __amdgpu_buffer_rsrc_t hin = (i & 1) ? hb1 : hb0, hout = (i & 1) ? hb0 : hb1;
     // ================================================================ owners: per-sequence work
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int s = cu + k * C;                   // uniform
-      if (k >= NOWN || s >= 16) break;
-      bool& fin = k ? fin1 : fin0;
-      int& mylen = k ? mylen1 : mylen0;
-      const int row = row0 + s;
-      const bool rowok = row < B;
-      float* sold = stk + ((size_t)k * 2 + (i & 1)) * DW;
-      float* snew = stk + ((size_t)k * 2 + ((i + 1) & 1)) * DW;
-      // ---- extras of sequence s.  Every lane reads its slice of the hidden state straight out of the
-      // packed blocks (unit 16*kg + 4*kq + c sits in lane s + 16*kq of block kg): no staging, no barrier
-      {
+    // (1) hidden states of the owned sequences -> LDS (unit 16*kg + 4*kq + c sits in lane s + 16*kq of block kg)
+    for (int t = tid; t < nown * (H / 4); t += FC_THREADS) {
+      const int k = t / (H / 4), u4 = t - k * (H / 4);
+      const int sg = cu + k * C, r = sg >> 4, s = sg & 15;
+      const float4 v = xld4(hin, (unsigned)(((r * KG + (u4 >> 2)) * 64 + s + 16 * (u4 & 3)) * 4) * 4u);
+      *reinterpret_cast<float4*>(hls + (size_t)k * H + 4 * u4) = v;
+    }
+    __syncthreads();
+    FC_TICK(0)
+    // (2) extras of every owned sequence: one pass over the weights (registers; later chunks from L2) for all of them
+    for (int c = 0; c < NCH; ++c) {
+      if (c > 0) load_chunk(c);
+      for (int k = 0; k < nown; ++k) {
         f32x4 hv[HM];
 #pragma unroll
-        for (int m = 0; m < HM; ++m) {
-          const float4 v = xld4(hin, (unsigned)((((l16 >> 2) + 4 * m) * 64 + s + 16 * (l16 & 3)) * 4) * 4u);
-          hv[m] = (f32x4){v.x, v.y, v.z, v.w};
-        }
-        for (int c = 0; c < NCH; ++c) {
-          if (c > 0) load_chunk(c);
+        for (int m = 0; m < HM; ++m) hv[m] = ld4(hls + (size_t)k * H + 4 * l16 + 64 * m);
 #pragma unroll
-          for (int r = 0; r < RC; ++r) {
-            const int n = rgrp + 32 * (c * RC + r);
-            float acc = 0.0f;
+        for (int rr = 0; rr < RC; ++rr) {
+          const int n = rgrp + 32 * (c * RC + rr);
+          float acc = 0.0f;
 #pragma unroll
-            for (int m = 0; m < HM; ++m) {
-              acc = fmaf(wreg[r * HM + m][0], hv[m][0], acc); acc = fmaf(wreg[r * HM + m][1], hv[m][1], acc);
-              acc = fmaf(wreg[r * HM + m][2], hv[m][2], acc); acc = fmaf(wreg[r * HM + m][3], hv[m][3], acc);
-            }
-            acc = row16_sum(acc);
-            if (l16 == 0 && n < NX) xex[n] = acc + bxl[n];
+          for (int m = 0; m < HM; ++m) {
+            acc = fmaf(wreg[rr * HM + m][0], hv[m][0], acc); acc = fmaf(wreg[rr * HM + m][1], hv[m][1], acc);
+            acc = fmaf(wreg[rr * HM + m][2], hv[m][2], acc); acc = fmaf(wreg[rr * HM + m][3], hv[m][3], acc);
           }
+          acc = row16_sum(acc);
+          if (l16 == 0 && n < NX) xexs[k * 256 + n] = acc + bxl[n];
         }
-        if (NCH > 1 && k + 1 < NOWN) load_chunk(0);   // registers hold the last chunk: first one back for the next sequence
       }
-      FC_TICK(0)
-      __syncthreads();
-      FC_TICK(1)
-      // ---- consume the logits of step i-1 (wave 0, lanes 0..31: entry v sits in lane v & 31)
+    }
+    __syncthreads();
+    FC_TICK(1)
+    // (3) one WAVE per owned sequence from here to the record: logits of step i-1 -> token, stack controls,
+    // row 0 of the new stack, publish.  Nothing below needs a workgroup barrier.
+    for (int k = wave; k < nown; k += 8) {
+      const int sg = cu + k * C;                  // wave-uniform: sequence of the cluster,
+      const int r = sg >> 4, s = sg & 15;         // its row group and row,
+      const int g = g0 + r;                       // the global row group
+      const int row = row00 + sg;
+      const bool rowok = row < B;
+      const float* xex = xexs + k * 256;
+      const float* sold = stk + ((size_t)k * 2 + (i & 1)) * DW;
+      float* snew = stk + ((size_t)k * 2 + ((i + 1) & 1)) * DW;
+      // ---- consume the logits of step i-1 (lanes 0..31: entry v sits in lane v & 31)
       int tok = teacher ? ((rowok && i < N + 1) ? min(max((int)a.tok_in[(size_t)min(i, N) * B + row], 0), V - 1) : 0) : a.start_tok;
-      if (i >= 1 && wave == 0 && lane < 32) {
+      int finflag = rowok ? 0 : 1;
+      if (i >= 1 && lane < 32) {
         const int l5 = lane;
         const float* lg = xex + 3 + W;
         if (teacher) {
           float m = -INFINITY;
+#pragma unroll 1
           for (int v = l5; v < V; v += 32) m = fmaxf(m, lg[v]);
 #pragma unroll
           for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 32));
           float total = 0.0f;
+#pragma unroll 1
           for (int v = l5; v < V; v += 32) total += __expf(lg[v] - m);
 #pragma unroll
           for (int o = 16; o >= 1; o >>= 1) total += __shfl_xor(total, o, 32);
@@ -303,8 +366,10 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
           }
           float* pr = a.PR + ((size_t)(i - 1) * G + g) * a.VP * 16;
           const float inv = __builtin_amdgcn_rcpf(total);
+#pragma unroll 2
           for (int v = l5; v < V; v += 32) pr[v * 16 + s] = __expf(lg[v] - m) * inv;
         } else {
+          bool fin = osi[k * 8 + 5] != 0;
           const bool greedy = !(a.temperature > 0.0f);
           if (greedy) {
             float bv = -INFINITY; int bi = 0x7fffffff;
@@ -322,7 +387,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
             for (int v = l5; v < V; v += 32) m = fmaxf(m, lg[v] / T);
 #pragma unroll
             for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 32));
-            const float u = k ? u1 : u0;          // pmg_uniform(seed, global row, offset + i - 1), formed under barrier B
+            const float u = osm[k * 8 + 3];       // pmg_uniform(seed, global row, offset + i - 1), formed under barrier B
             // running CDF: slot ks holds entries 32ks..32ks+31, one per lane (3+W+V <= 256 on this path)
             float cdf[8];
             float carry = 0.0f;
@@ -354,16 +419,17 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
             if (tok < 0) tok = V - 1;
           }
           if (rowok && l5 == 0) a.tok_out[(size_t)row * N + (i - 1)] = tok;
-          if (!fin && tok == a.stop_tok) { fin = true; mylen = i - 1; }
+          if (!fin && tok == a.stop_tok) {
+            fin = true;
+            if (l5 == 0) { osi[k * 8 + 5] = 1; osi[k * 8 + 6] = i - 1; }
+          }
+          if (fin) finflag = 1;
         }
-        if (l5 == 0) { misc[2] = tok; misc[3] = (fin || !rowok) ? 1 : 0; }
-      } else if (i == 0 && tid == 0) {
-        misc[2] = tok; misc[3] = rowok ? 0 : 1;
       }
-      __syncthreads();
+      tok = __shfl(tok, 0);
+      finflag = __shfl(finflag, 0);
       FC_TICK(2)
       if (i < N) {
-        tok = misc[2];
         // ---- stack controls; ROW 0 of the new stack (= the stack top the gates need) and the record
         // go out first: the rest of the update and every history store wait until this member has
         // arrived at barrier A (below), off the chain the other members wait on
@@ -372,35 +438,31 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
         const float e0 = __expf(c0 - m), e1 = __expf(c1 - m), e2 = __expf(c2 - m);
         const float inv = 1.0f / ((e0 + e1) + e2);
         const float apush = e0 * inv, apop = e1 * inv, anoop = e2 * inv;
-        if (wave == 0) {
-          float top = 0.0f, pv = 0.0f;
-          if (lane < W) {
-            pv = fast_tanh(xex[3 + lane]);
-            const float nxt = (1 < D) ? sold[W + lane] : 0.0f;
-            top = anoop * sold[lane] + apush * pv + apop * nxt;
-            snew[lane] = top;
-          }
-          xst1(rec, (unsigned)(s * 128 + lane) * 4u, top);
-          const float meta = (lane == 0) ? __int_as_float(tok) : (lane == 1) ? __int_as_float(misc[3]) : 0.0f;
-          xst1(rec, (unsigned)(s * 128 + 64 + lane) * 4u, meta);
-          if (k) { pv1 = pv; top1 = top; } else { pv0 = pv; top0 = top; }
-          if (lane == 0) { fm[4 * k] = apush; fm[4 * k + 1] = apop; fm[4 * k + 2] = anoop; misc[8 + k] = tok; }
+        float top = 0.0f, pv = 0.0f;
+        if (lane < W) {
+          pv = fast_tanh(xex[3 + lane]);
+          const float nxt = (1 < D) ? sold[W + lane] : 0.0f;
+          top = anoop * sold[lane] + apush * pv + apop * nxt;
+          snew[lane] = top;
         }
+        xst1(rec, (unsigned)(sg * 128 + lane) * 4u, top);
+        const float meta = (lane == 0) ? __int_as_float(tok) : (lane == 1) ? __int_as_float(finflag) : 0.0f;
+        xst1(rec, (unsigned)(sg * 128 + 64 + lane) * 4u, meta);
+        ptv[k * 128 + lane] = pv; ptv[k * 128 + 64 + lane] = top;
+        if (lane == 0) { osm[k * 8] = apush; osm[k * 8 + 1] = apop; osm[k * 8 + 2] = anoop; osi[k * 8 + 4] = tok; }
       }
-      if (k + 1 < NOWN) __syncthreads();         // xex is reused by the next owned sequence
     }
     FC_TICK(3)
     if (i == N) break;
     FC_ARRIVE();
     // ---- deferred owner work, under the wait of barrier A: stack rows >= 1 and the teacher history
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int s = cu + k * C;
-      if (k >= NOWN || s >= 16) break;
-      const bool rowok = row0 + s < B;
+    for (int k = 0; k < nown; ++k) {
+      const int sg = cu + k * C;
+      const int s = sg & 15, g = g0 + (sg >> 4);
+      const bool rowok = row00 + sg < B;
       const float* sold = stk + ((size_t)k * 2 + (i & 1)) * DW;
       float* snew = stk + ((size_t)k * 2 + ((i + 1) & 1)) * DW;
-      const float apush = fm[4 * k], apop = fm[4 * k + 1], anoop = fm[4 * k + 2];
+      const float apush = osm[k * 8], apop = osm[k * 8 + 1], anoop = osm[k * 8 + 2];
       // rows that hold data after this update: d <= min(i, D-1) (row d is zero until step d)
       const int dhi = (i < D - 1) ? i : D - 1;
       for (int d = 1 + sd0; d <= dhi; d += SDS) {       // thread (sd0, sw): column sw of rows 1 + sd0 + j*SDS
@@ -415,7 +477,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
       }
       if (teacher) {
         if (wave == 0 && lane < W) {
-          const float pv = k ? pv1 : pv0, top = k ? top1 : top0;
+          const float pv = ptv[k * 128 + lane], top = ptv[k * 128 + 64 + lane];
           a.SB[((size_t)(i + 1) * G + g) * a.SW + (size_t)lane * 16 + s] = top;
           a.PV[((size_t)i * G + g) * 1024 + lane * 16 + s] = pv;
           a.TP[((size_t)i * G + g) * 2048 + lane * 16 + s] = top;
@@ -424,85 +486,76 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
           a.CT[((size_t)i * G + g) * 64 + (tid - 128) * 16 + s] = (tid == 128) ? apush : (tid == 129) ? apop : anoop;
         // one-hot rows of the fed token behind the stack-top rows (weight-gradient B operand, V <= 64)
         if (tid >= 64 && tid < 128)
-          a.TP[((size_t)i * G + g) * 2048 + (size_t)tid * 16 + s] = (rowok && misc[8 + k] == tid - 64) ? 1.0f : 0.0f;
+          a.TP[((size_t)i * G + g) * 2048 + (size_t)tid * 16 + s] = (rowok && osi[k * 8 + 4] == tid - 64) ? 1.0f : 0.0f;
       }
     }
-    if (!(ok = FC_WAIT())) break;                // A: tokens and stack tops of all 16 sequences visible
+    if (!(ok = FC_WAIT())) break;                // A: tokens and stack tops of every sequence visible
 
     FC_TICK(4)
-    // ================================================================ members: gates of the own 16 units
-    {
-      // K split: waves 0-3 carry the r and z tiles, waves 4-7 the n tile (input and hidden part apart)
-      const int kw = wave & 3;
-      const int kq0 = kw * (KG / 4);
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    // ================================================================ members: gates of the own 16 units, group by group
+    int allfin = 1;                                          // wave 1, decode: every sequence so far has finished
+    for (int r = 0; r < NGc; ++r) {
+      float* redr = red + (size_t)(r & 1) * 8 * 2 * 256;
+      f32x4 acc0 = z4, acc1 = z4;
       // every exchanged operand of this wave is requested up front: one L2 round trip, not one per k group
-      const float4 xt = xld4(rec, (unsigned)(b * 128 + 16 * kw + 4 * q) * 4u);       // stack-top k group kw
+      const float4 xt = xld4(rec, (unsigned)((r * 16 + b) * 128 + 16 * kw + 4 * q) * 4u);       // stack-top k group kw
       float4 xs[HM];
 #pragma unroll
-      for (int m = 0; m < HM; ++m) xs[m] = xld4(hin, (unsigned)((kq0 + m) * 256 + lane * 4) * 4u);
+      for (int m = 0; m < HM; ++m) xs[m] = xld4(hin, (unsigned)((r * KG + kq0 + m) * 256 + lane * 4) * 4u);
       float tkf = 0.0f;
-      if (wave == 0) tkf = xld1(rec, (unsigned)(b * 128 + 64) * 4u);                  // token fed to row b at this step
+      if (wave == 0) tkf = xld1(rec, (unsigned)((r * 16 + b) * 128 + 64) * 4u);                  // token fed to row b at this step
+      int fl = 1;
+      if (decode && wave == 1 && lane < 16) fl = __float_as_int(xld1(rec, (unsigned)((r * 16 + lane) * 128 + 65) * 4u));
       if (wave < 4) {
 #pragma unroll
         for (int m = 0; m < HM; ++m) {
-          const int kg = kq0 + m;
           const float4 x = xs[m];
-          const f32x4 wr = ld4(wl_hh + (size_t)(0 * KG + kg) * 256 + lane * 4), wz = ld4(wl_hh + (size_t)(1 * KG + kg) * 256 + lane * 4);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0], x.x, acc0, 0, 0, 0);
+          f32x4 wz;
+          if constexpr (ZREG) wz = wres[HM + m]; else wz = ld4(wlz + (size_t)(kq0 + m) * 256 + lane * 4);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][0], x.x, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[0], x.x, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1], x.y, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][1], x.y, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[1], x.y, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[2], x.z, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][2], x.z, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[2], x.z, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[3], x.w, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][3], x.w, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[3], x.w, acc1, 0, 0, 0);
         }
-        const f32x4 wr = ld4(wl_is + (size_t)(0 * 4 + kw) * 256 + lane * 4), wz = ld4(wl_is + (size_t)(1 * 4 + kw) * 256 + lane * 4);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0], xt.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[0], xt.x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1], xt.y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[1], xt.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[2], xt.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[2], xt.z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[3], xt.w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[3], xt.w, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis0[0], xt.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis1[0], xt.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis0[1], xt.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis1[1], xt.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis0[2], xt.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis1[2], xt.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis0[3], xt.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis1[3], xt.w, acc1, 0, 0, 0);
       } else {
 #pragma unroll
         for (int m = 0; m < HM; ++m) {            // acc1 = W_hn h
-          const int kg = kq0 + m;
           const float4 x = xs[m];
-          const f32x4 wn = ld4(wl_hh + (size_t)(2 * KG + kg) * 256 + lane * 4);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[0], x.x, acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[1], x.y, acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[2], x.z, acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[3], x.w, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][0], x.x, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][1], x.y, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][2], x.z, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][3], x.w, acc1, 0, 0, 0);
         }
-        const f32x4 wn = ld4(wl_is + (size_t)(2 * 4 + kw) * 256 + lane * 4);   // acc0 = W_in[:, E:] top
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[0], xt.x, acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[1], xt.y, acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[2], xt.z, acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[3], xt.w, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis0[0], xt.x, acc0, 0, 0, 0);   // acc0 = W_in[:, E:] top
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis0[1], xt.y, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis0[2], xt.z, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis0[3], xt.w, acc0, 0, 0, 0);
       }
-      st4(red + (size_t)(wave * 2 + 0) * 256 + lane * 4, acc0);
-      st4(red + (size_t)(wave * 2 + 1) * 256 + lane * 4, acc1);
-      // finished flags of the 16 sequences: ONE load per lane of wave 1 (lane s reads the flag of sequence
-      // s), combined by a ballot and handed to everybody through LDS behind the barrier below
-      if (decode && wave == 1) {
-        const int fl = (lane < 16) ? __float_as_int(xld1(rec, (unsigned)(lane * 128 + 65) * 4u)) : 1;
-        const int all1 = __all(fl != 0);
-        if (lane == 0) misc[4] = (all1 && !(a.flags & PMG_FLAG_NO_EARLY_EXIT)) ? 1 : 0;
-      }
-      __syncthreads();
-      const int alld = decode ? misc[4] : 0;
+      st4(redr + (size_t)(wave * 2 + 0) * 256 + lane * 4, acc0);
+      st4(redr + (size_t)(wave * 2 + 1) * 256 + lane * 4, acc1);
+      // finished flags of the group's 16 sequences: ONE load per lane of wave 1, combined by a ballot
+      if (decode && wave == 1) allfin = (allfin && __all(fl != 0)) ? 1 : 0;
+      __syncthreads();                            // partials of group r visible (the other buffer is being read by nobody)
       if (wave == 0) {
-        f32x4 vr = {0.f, 0.f, 0.f, 0.f}, vz = vr, vi = vr, vh = vr;
+        f32x4 vr = z4, vz = z4, vi = z4, vh = z4;
 #pragma unroll
         for (int wv = 0; wv < 4; ++wv) {
-          vr += ld4(red + (size_t)(wv * 2 + 0) * 256 + lane * 4);
-          vz += ld4(red + (size_t)(wv * 2 + 1) * 256 + lane * 4);
-          vi += ld4(red + (size_t)((wv + 4) * 2 + 0) * 256 + lane * 4);
-          vh += ld4(red + (size_t)((wv + 4) * 2 + 1) * 256 + lane * 4);
+          vr += ld4(redr + (size_t)(wv * 2 + 0) * 256 + lane * 4);
+          vz += ld4(redr + (size_t)(wv * 2 + 1) * 256 + lane * 4);
+          vi += ld4(redr + (size_t)((wv + 4) * 2 + 0) * 256 + lane * 4);
+          vh += ld4(redr + (size_t)((wv + 4) * 2 + 1) * 256 + lane * 4);
         }
         const int tk = __float_as_int(tkf);
         if (gt_lds) {
@@ -513,44 +566,59 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
           vr += ld4(gt); vz += ld4(gt + H); vi += ld4(gt + 2 * H);
         }
         vh += bhn;
-        f32x4 r, z, n, hn;
+        const f32x4 hown = ld4(hl + r * 256 + lane * 4);
+        f32x4 rg, zg, ng, hn;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          r[j] = fast_sigmoid(vr[j]);
-          z[j] = fast_sigmoid(vz[j]);
-          n[j] = fast_tanh(vi[j] + r[j] * vh[j]);
-          hn[j] = (hown[j] - n[j]) * z[j] + n[j];
+          rg[j] = fast_sigmoid(vr[j]);
+          zg[j] = fast_sigmoid(vz[j]);
+          ng[j] = fast_tanh(vi[j] + rg[j] * vh[j]);
+          hn[j] = (hown[j] - ng[j]) * zg[j] + ng[j];
         }
-        hown = hn;
-        if (!alld) xst4(hout, (unsigned)(cu * 256 + lane * 4) * 4u, hn);
-        if (teacher) { gr = r; gz = z; gn = n; gvh = vh; }      // history: stored after the arrive of barrier B
-      }
-      if (alld) {
-        // every row of this cluster has emitted stop_tok: owners fill their rows' tails and all leave
-        for (int k = 0; k < NOWN; ++k) {
-          const int s = cu + k * C;
-          if (s < 16 && row0 + s < B)
-            for (int t = i + tid; t < N; t += FC_THREADS) a.tok_out[(size_t)(row0 + s) * N + t] = a.stop_tok;
+        st4(hl + r * 256 + lane * 4, hn);
+        xst4(hout, (unsigned)((r * KG + cu) * 256 + lane * 4) * 4u, hn);
+        if (teacher) {
+          if (r + 1 < NGc) {
+            // history of the earlier groups goes out right away (it drains under the next group's product)
+            float* gp = a.GT[0] + (((size_t)i * G + g0 + r) * KG + cu) * 1024 + lane * 4;
+            st4(gp, rg); st4(gp + 256, zg); st4(gp + 512, ng); st4(gp + 768, vh);
+            float* hh = a.HH[0] + (((size_t)(i + 1) * G + g0 + r) * H + 16 * cu + 4 * q) * 16 + b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hh[j * 16] = hn[j];
+          } else {
+            // the last group's goes behind the arrive of barrier B (through LDS: hl holds the new state)
+            st4(ghl + lane * 4, rg); st4(ghl + 256 + lane * 4, zg); st4(ghl + 512 + lane * 4, ng); st4(ghl + 768 + lane * 4, vh);
+          }
         }
-        break;
       }
     }
+    if (decode && wave == 1 && lane == 0) misc[4] = (allfin && !(a.flags & PMG_FLAG_NO_EARLY_EXIT)) ? 1 : 0;
     FC_TICK(5)
     FC_ARRIVE();
-    if (teacher && wave == 0) {
-      float* gp = a.GT[0] + (((size_t)i * G + g) * KG + cu) * 1024 + lane * 4;
-      st4(gp, gr); st4(gp + 256, gz); st4(gp + 512, gn); st4(gp + 768, gvh);
-      float* hh = a.HH[0] + (((size_t)(i + 1) * G + g) * H + 16 * cu + 4 * q) * 16 + b;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) hh[j * 16] = hown[j];
+    if (decode && misc[4]) {
+      // every row of this cluster has emitted stop_tok: owners fill their rows' tails and all leave
+      for (int k = 0; k < nown; ++k) {
+        const int row = row00 + cu + k * C;
+        if (row < B)
+          for (int t = i + tid; t < N; t += FC_THREADS) a.tok_out[(size_t)row * N + t] = a.stop_tok;
+      }
+      break;
     }
-    if (owner) {
+    if (teacher && wave == 0) {
+      const int r = NGc - 1;
+      float* gp = a.GT[0] + (((size_t)i * G + g0 + r) * KG + cu) * 1024 + lane * 4;
+      st4(gp, ld4(ghl + lane * 4)); st4(gp + 256, ld4(ghl + 256 + lane * 4));
+      st4(gp + 512, ld4(ghl + 512 + lane * 4)); st4(gp + 768, ld4(ghl + 768 + lane * 4));
+      const f32x4 hn = ld4(hl + r * 256 + lane * 4);
+      float* hh = a.HH[0] + (((size_t)(i + 1) * G + g0 + r) * H + 16 * cu + 4 * q) * 16 + b;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hh[j * 16] = hn[j];
+    }
+    if (nown > 0) {
       // under the wait: what the next step's owner phase needs and the exchange does not carry
       load_chunk(0);
-      if (decode && wave == 0) {
-        u0 = pmg_uniform(a.seed, (uint64_t)(a.seq_base + row0 + cu), a.offset + (uint64_t)i);
-        if (NOWN > 1) u1 = pmg_uniform(a.seed, (uint64_t)(a.seq_base + row0 + cu + C), a.offset + (uint64_t)i);
-      }
+      if (decode && wave == 0 && lane < nown)
+        osm[lane * 8 + 3] = pmg_uniform(a.seed, (uint64_t)(a.seq_base + row00 + cu + lane * C), a.offset + (uint64_t)i);
     }
     if (!(ok = FC_WAIT())) break;                // B: the new hidden state of every member visible
     FC_TICK(6)
@@ -564,62 +632,72 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
   // ---------------------------------------------------------------- epilogue
   if (!ok) {
     // gave up on a barrier: poison what the caller will look at
-    for (int k = 0; k < NOWN; ++k) {
-      const int s = cu + k * C;
-      if (s < 16 && row0 + s < B) {
-        if (decode && tid == 0) a.len_out[row0 + s] = -1;
-        if (teacher) for (int t = tid; t < N; t += FC_THREADS) a.logp_out[(size_t)t * B + row0 + s] = __int_as_float(0x7fc00000);
+    for (int k = 0; k < nown; ++k) {
+      const int row = row00 + cu + k * C;
+      if (row < B) {
+        if (decode && tid == 0) a.len_out[row] = -1;
+        if (teacher) for (int t = tid; t < N; t += FC_THREADS) a.logp_out[(size_t)t * B + row] = __int_as_float(0x7fc00000);
       }
     }
     return;
   }
+  __syncthreads();
   if (decode && tid == 0)
-    for (int k = 0; k < NOWN; ++k) {
-      const int s = cu + k * C;
-      if (s < 16 && row0 + s < B) a.len_out[row0 + s] = k ? mylen1 : mylen0;
+    for (int k = 0; k < nown; ++k) {
+      const int row = row00 + cu + k * C;
+      if (row < B) a.len_out[row] = osi[k * 8 + 6];
     }
-  if (a.h_out != nullptr && wave == 0 && row0 + b < B) st4(a.h_out + (size_t)(row0 + b) * H + 16 * cu + 4 * q, hown);
+  if (a.h_out != nullptr && wave == 0)
+    for (int r = 0; r < NGc; ++r)
+      if (row00 + 16 * r + b < B) st4(a.h_out + (size_t)(row00 + 16 * r + b) * H + 16 * cu + 4 * q, ld4(hl + r * 256 + lane * 4));
 }
 
-size_t fwdc_lds_base_bytes(const FwdArgs* a) {
-  const int KG = a->H / 16, nown = (16 + KG - 1) / KG;
-  return ((size_t)3 * KG * 256 + 3 * 4 * 256 + 8 * 2 * 256 + 256 + 256 + (size_t)nown * 2 * a->D * a->W + 64) * sizeof(float);
+// groups per cluster, owned sequences per member, LDS bytes without / with the token-table lines
+int fwdc_nown(const FwdArgs* a, int ng) { const int C = a->H / 16; return (16 * ng + C - 1) / C; }
+size_t fwdc_lds_base_bytes(const FwdArgs* a, int ng) {
+  return (size_t)fc_lds(a->H, ng, fwdc_nown(a, ng), a->D * a->W).gtl * sizeof(float);
 }
-
-bool fwdc_gtab_fits(const FwdArgs* a) { return fwdc_lds_base_bytes(a) + (size_t)a->V * 48 * 4 <= (size_t)160 * 1024; }
-size_t fwdc_lds_bytes(const FwdArgs* a) {
-  return fwdc_lds_base_bytes(a) + (fwdc_gtab_fits(a) ? (size_t)a->V * 48 * 4 : 0);
+bool fwdc_gtab_fits(const FwdArgs* a, int ng) { return fwdc_lds_base_bytes(a, ng) + (size_t)a->V * 48 * 4 <= (size_t)160 * 1024; }
+size_t fwdc_lds_bytes(const FwdArgs* a, int ng) {
+  return fwdc_lds_base_bytes(a, ng) + (fwdc_gtab_fits(a, ng) ? (size_t)a->V * 48 * 4 : 0);
 }
 
 }  // namespace
 
-// Floats of the exchange region and words of the counter region for G clusters (both modes).
-size_t pmg_fwdc_cx_floats(const PmgDims& d) { return (size_t)d.G * ((size_t)2 * d.H * 16 + 16 * 128); }
+// Floats of the exchange region and words of the counter region (both modes): NG row groups per
+// cluster, ceil(G / NG) clusters.
+size_t pmg_fwdc_cx_floats(const PmgDims& d) {
+  const size_t ng = pmg_cluster_ng(d.G, d.H), ncl = (d.G + ng - 1) / ng;
+  return ncl * ng * ((size_t)2 * d.H * 16 + 16 * 128);
+}
 size_t pmg_fwdc_sync_words(const PmgDims& d) { return (size_t)32 * (1 + d.G); }
 
-// The clustered kernel serves: one layer, hidden 128..512 (a cluster is H/16 <= 32 CUs), at most
-// 8 * floor(32 / C) row groups (every cluster resident at once), extras of at most 256 rows, decode
-// or teacher-forced mode, and a per-workgroup state that fits the LDS.
+// The clustered kernel serves: one layer, hidden 128..512 (a cluster is H/16 <= 32 CUs, at most
+// 8 * floor(32 / C) clusters so that every one is resident at once), up to PMG_CLUSTER_NG_MAX row groups
+// per cluster as far as the owned sequences' stacks fit the LDS, extras of at most 256 rows, decode or
+// teacher-forced mode.
 bool pmg_fwdc_applicable(const FwdArgs* a) {
   if (a->flags & PMG_FLAG_NO_CLUSTER) return false;
   if (a->mode != PMG_FWD_DECODE && a->mode != PMG_FWD_TEACHER) return false;
   if (a->L != 1 || a->H > 512 || a->NX > 256 || a->CX == nullptr) return false;
-  const int C = a->H / 16;
-  if (a->G > 8 * (32 / C)) return false;
-  return fwdc_lds_base_bytes(a) <= (size_t)160 * 1024;
+  const int ng = pmg_cluster_ng(a->G, a->H);
+  if (ng > PMG_CLUSTER_NG_MAX) return false;
+  return fwdc_lds_base_bytes(a, ng) <= (size_t)160 * 1024;
 }
 
 hipError_t pmg_launch_fwdc(const FwdArgs* a0, hipStream_t st) {
   FwdArgs args = *a0;
-  args.cluster_gtab_lds = fwdc_gtab_fits(a0) ? 1 : 0;
+  const int ng = pmg_cluster_ng(a0->G, a0->H), ncl = (a0->G + ng - 1) / ng;
+  args.cluster_ng = ng;
+  args.cluster_gtab_lds = fwdc_gtab_fits(a0, ng) ? 1 : 0;
   const FwdArgs* a = &args;
   const int C = a->H / 16;
-  size_t lds = fwdc_lds_bytes(a);
+  size_t lds = fwdc_lds_bytes(a, ng);
   if (lds < (size_t)81 * 1024) lds = (size_t)81 * 1024;     // more than half a CU: one workgroup per CU
   // counters and the status word start at zero (stream-ordered; 128 B per counter)
-  hipError_t e = hipMemsetAsync(a->CXS, 0, (size_t)32 * (1 + a->G) * sizeof(unsigned), st);
+  hipError_t e = hipMemsetAsync(a->CXS, 0, (size_t)32 * (1 + ncl) * sizeof(unsigned), st);
   if (e != hipSuccess) return e;
-  const int grid = 8 * C * ((a->G + 7) / 8);
+  const int grid = 8 * C * ((ncl + 7) / 8);
 #define FC_LAUNCH(MODE_, HM_)                                                                              \
   {                                                                                                        \
     static std::atomic<unsigned long long> done{0};                                                        \

@@ -94,11 +94,19 @@ struct FwdArgs {
   // clustered forward (pmg_fwdc.hip): exchange buffers, counters, and the extras in torch layout
   float* CX; unsigned* CXS;
   int cluster_gtab_lds;    // set by pmg_launch_fwdc: the token-table lines of a member's units fit its LDS
+  int cluster_ng;          // set by pmg_launch_fwdc: row groups per cluster
   const float* w_ctrl; const float* b_ctrl; const float* w_push; const float* b_push;
   const float* w_out; const float* b_out;
 };
 
 hipError_t pmg_launch_fwd(const FwdArgs* a, hipStream_t st);
+// Clustered kernels: a cluster is H/16 workgroups, at most 8 * floor(32 / (H/16)) clusters are resident
+// at once; more row groups than that are served NG per cluster.
+#define PMG_CLUSTER_NG_MAX 16
+static inline int pmg_cluster_ng(int G, int H) {
+  const int ncl = 8 * (32 / (H / 16));
+  return (G + ncl - 1) / ncl;
+}
 // clustered forward for small batches (pmg_fwdc.hip); pmg_launch_fwd picks it by shape
 bool pmg_fwdc_applicable(const FwdArgs* a);
 hipError_t pmg_launch_fwdc(const FwdArgs* a, hipStream_t st);
