@@ -78,57 +78,94 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
+// LDS map (float offsets), shared by the kernel and the host-side size check.
+struct BcLds { unsigned wt_is, wt_x, red, dtl, dxl, r3, own, sprev, dsb, misc, end; };
+__host__ __device__ inline BcLds bc_lds(const int NXT, const int NOWN, const int DW) {
+  BcLds o;
+  unsigned p = 0;
+  o.wt_is = p; p += 12 * 256;               // [4][3][64][4]  own gate rows' part of W_ih[:, E:]^T
+  o.wt_x = p; p += (unsigned)NXT * 256;     // [NXT][64][4]   rows 16cu.. of [ctrl; push; out]^T
+  o.red = p; p += 2 * 8 * 256;              // [2][8][256] K-split partials (double-buffered over the groups); owners: [C][64] dtop partials
+  o.dtl = p; p += 64;                       // [64] dtop of the sequence being served
+  o.dxl = p; p += 256;                      // [256] dx of the sequence being served
+  o.r3 = p; p += 32;                        // [8][4] control-gradient partials per wave
+  o.own = p; p += (unsigned)NOWN * 2;       // [NOWN][2] reward | sum_p R * logp of the owned sequences
+  o.sprev = p; p += (unsigned)DW;           // [D*W] S_{p-1} of the sequence being served
+  o.dsb = p; p += (unsigned)NOWN * 2 * DW;  // [NOWN][2][D*W] stack gradient ping-pong
+  o.misc = p; p += 64;
+  o.end = p;
+  return o;
+}
+
 // HM = H / 64.  One layer.
+//
+// Like the forward (pmg_fwdc.hip) a cluster serves NG <= 8 consecutive row groups: the two barriers of a
+// step are shared by the groups; sequence sigma = 16 r + s of the cluster is OWNED by member sigma % C.
+// What is per (own units, group) -- the carry, the cell backward, the partial dtop, the extras product --
+// belongs to WAVE r of the member, in registers, with no workgroup barrier; the W_hh^T product of a
+// group is split over the eight waves along K (each keeps its slice of the rows of W_hh^T in registers).
 template <int HM>
 __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int H = 64 * HM, KG = H / 16, C = KG, UPW = H / 128 > 0 ? H / 128 : 1, KG3 = 3 * H / 16;
+  constexpr int H = 64 * HM, KG = H / 16, C = KG, UPW = H / 128 > 0 ? H / 128 : 1, KG3 = 3 * H / 16, KPW = KG3 / 8;
   static_assert(H % 128 == 0, "hidden size is a multiple of 128");
-  const int W = a.W, D = a.D, V = a.V, B = a.B, G = a.G, N = a.N, NX = a.NX, NXT = a.NXT;
+  const int W = a.W, D = a.D, V = a.V, B = a.B, G = a.G, N = a.N, NXT = a.NXT;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = lane & 15, q = lane >> 4;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int gsub = slot / C, cu = slot - gsub * C;
-  const int g = gsub * 8 + xcd;
-  if (g >= G) return;
-  const int row0 = g * PMG_ROWS;
-  const int NOWN = (16 + C - 1) / C;
+  const int csub = slot / C, cu = slot - csub * C;
+  const int cl = csub * 8 + xcd;
+  const int NG = a.cluster_ng;
+  const int g0 = cl * NG;
+  if (g0 >= G) return;
+  const int NGc = (G - g0 < NG) ? G - g0 : NG;
+  const int NS = 16 * NGc;
+  const int NOWN = (16 * NG + C - 1) / C;
+  const int nown = (cu < NS) ? (NS - cu + C - 1) / C : 0;
+  const int row00 = g0 * PMG_ROWS;
   const int DW = D * W;
-  const bool owner = cu < 16;
+  const bool mygrp = wave < NGc;                 // this wave carries group r = wave of the own units
+  const int gw = g0 + wave;
 
   // ---- LDS
-  float* wt_hh = reinterpret_cast<float*>(smem);     // [KG3][64][4]   rows 16cu.. of W_hh^T (reduction in chunk order)
-  float* wt_is = wt_hh + KG3 * 256;                  // [4][3][64][4]  own gate rows' part of W_ih[:, E:]^T
-  float* wt_x = wt_is + 12 * 256;                    // [NXT][64][4]   rows 16cu.. of [ctrl; push; out]^T
-  float* red = wt_x + (size_t)NXT * 256;             // [8][256] K-split partials; owners: [C][64] dtop partials
-  float* dgl = red + 8 * 256;                        // [4][256] own dr | dz | dn | dghn, D layout
-  float* dtl = dgl + 4 * 256;                        // [64] dtop of the sequence being served
-  float* dxl = dtl + 64;                             // [256] dx of the sequence being served
-  float* r3 = dxl + 256;                             // [8][4] control-gradient partials per wave
-  float* sprev = r3 + 32;                            // [D*W] S_{p-1} of the sequence being served
-  float* dsb = sprev + DW;                           // [NOWN][2][D*W] stack gradient ping-pong
-  int* misc = reinterpret_cast<int*>(dsb + (size_t)NOWN * 2 * DW);
+  const BcLds lo = bc_lds(NXT, NOWN, DW);
+  float* fs = reinterpret_cast<float*>(smem);
+  float* wt_is = fs + lo.wt_is;
+  float* wt_x = fs + lo.wt_x;
+  float* red = fs + lo.red;
+  float* dtl = fs + lo.dtl;
+  float* dxl = fs + lo.dxl;
+  float* r3 = fs + lo.r3;
+  float* own = fs + lo.own;
+  float* sprev = fs + lo.sprev;
+  float* dsb = fs + lo.dsb;
+  int* misc = reinterpret_cast<int*>(fs + lo.misc);
 
-  // ---- exchange buffers of this cluster (floats): dg blocks [2][3][C][256] | partial dtop [C][4][256] |
-  //      dx records [16][256] | loss records [16][64]
-  const size_t o_dg = 0, o_pt = (size_t)2 * 3 * C * 256, o_dx = o_pt + (size_t)C * 4 * 256, o_ls = o_dx + 16 * 256;
-  const size_t cxs = o_ls + 16 * 64;
-  float* cx = a.CX + (size_t)g * cxs;
-  const __amdgpu_buffer_rsrc_t dgb0 = pmg_rsrc(cx + o_dg, (unsigned)(3 * C * 256) * 4u);
-  const __amdgpu_buffer_rsrc_t dgb1 = pmg_rsrc(cx + o_dg + (size_t)3 * C * 256, (unsigned)(3 * C * 256) * 4u);
-  const __amdgpu_buffer_rsrc_t ptb = pmg_rsrc(cx + o_pt, (unsigned)(C * 4 * 256) * 4u);
-  const __amdgpu_buffer_rsrc_t dxb = pmg_rsrc(cx + o_dx, 16u * 1024u);
-  const __amdgpu_buffer_rsrc_t lsb = pmg_rsrc(cx + o_ls, 16u * 256u);
-  unsigned* ctr = a.CXS + 32 + (size_t)g * 32;
+  // ---- exchange buffers of this cluster (floats): dg blocks [2][NG][3][C][256] | partial dtop [NG][C][4][256] |
+  //      dx records [16 NG][256] | loss records [16 NG][64]
+  const size_t dgf = (size_t)NG * 3 * C * 256;
+  const size_t o_pt = 2 * dgf, o_dx = o_pt + (size_t)NG * C * 4 * 256, o_ls = o_dx + (size_t)NG * 16 * 256;
+  const size_t cxs = o_ls + (size_t)NG * 16 * 64;
+  float* cx = a.CX + (size_t)cl * cxs;
+  const __amdgpu_buffer_rsrc_t dgb0 = pmg_rsrc(cx, (unsigned)(dgf * 4));
+  const __amdgpu_buffer_rsrc_t dgb1 = pmg_rsrc(cx + dgf, (unsigned)(dgf * 4));
+  const __amdgpu_buffer_rsrc_t ptb = pmg_rsrc(cx + o_pt, (unsigned)(NG * C * 4 * 256) * 4u);
+  const __amdgpu_buffer_rsrc_t dxb = pmg_rsrc(cx + o_dx, (unsigned)NG * 16u * 1024u);
+  const __amdgpu_buffer_rsrc_t lsb = pmg_rsrc(cx + o_ls, (unsigned)NG * 16u * 256u);
+  unsigned* ctr = a.CXS + 32 + (size_t)cl * 32;
   unsigned* status = a.CXS;
   unsigned bars = 0;
 #define BC_ARRIVE() (++bars, cluster_arrive(ctr))
 #define BC_WAIT() cluster_wait(ctr, (unsigned)C * bars, status, misc)
 
-  // ---- resident transposed weights out of the packs
+  // ---- resident transposed weights out of the packs.  W_hh^T rows 16cu..: [KG3][64][4] in chunk order;
+  // wave w keeps reduction groups w*KPW .. w*KPW+KPW-1 in registers
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 wthh[KPW];
   {
-    const float* src = a.wbase + a.oWHHt[0] / 4 + (size_t)cu * KG3 * 256;
-    for (int i = tid * 4; i < KG3 * 256; i += BC_THREADS * 4) st4(wt_hh + i, ld4(src + i));
+    const float* src = a.wbase + a.oWHHt[0] / 4 + ((size_t)cu * KG3 + wave * KPW) * 256 + lane * 4;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) wthh[i] = ld4(src + (size_t)i * 256);
     // W_ih[:, E:]^T: tile t (16 stack columns), reduction group of (piece, unit tile cu) in chunk order
     const int kc = cu % UPW, kwv = cu / UPW;
     for (int i = tid * 4; i < 12 * 256; i += BC_THREADS * 4) {
@@ -142,29 +179,31 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
   for (int i = tid; i < NOWN * 2 * DW; i += BC_THREADS) dsb[i] = 0.0f;
   for (int i = tid; i < 256; i += BC_THREADS) dxl[i] = 0.0f;
   if (tid < 64) misc[tid] = 0;
+  if (tid < nown) {
+    const int row = row00 + cu + tid * C;
+    own[tid * 2] = (row < B) ? a.reward[row] : 0.0f;
+    own[tid * 2 + 1] = 0.0f;
+  }
   __syncthreads();
 
-  // stack thread mapping: thread -> (row offset sd0, column sw), rows sd0 + j*SDS (at most 8 per thread)
+  // stack thread mapping: thread -> (row offset sd0, column sw), rows sd0 + j*SDS
   const int SDS = BC_THREADS / W;
   const int sd0 = tid / W, sw = (sd0 < SDS) ? tid - sd0 * W : W;
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 car = z4;                       // wave 0: hidden-state gradient of the own units (D layout)
-  f32x4 dhz = z4;                       // wave 0: z * dh of this step
-  float lossacc0 = 0.f, lossacc1 = 0.f; // thread 0: sum_p R * logp of each owned row
-  const float R0 = (owner && row0 + cu < B) ? a.reward[row0 + cu] : 0.0f;
-  const float R1 = (owner && NOWN > 1 && cu + C < 16 && row0 + cu + C < B) ? a.reward[row0 + cu + C] : 0.0f;
+  f32x4 car = z4;                       // wave r: hidden-state gradient of the own units of group r (D layout)
+  f32x4 dhz = z4;                       // wave r: z * dh of this step
+  f32x4 hhs = z4;                       // wave r: W_hh^T [dr; dz; dghn] of this step
   bool ok = true;
 
   for (int p = N; p >= 0 && ok; --p) {
     const bool virt = (p == N);
     const __amdgpu_buffer_rsrc_t dgw = (p & 1) ? dgb1 : dgb0;
-    // ================================================================ members: cell backward of the own units
-    f32x4 gr = z4, gz = z4, gn = z4, gg = z4;      // wave 0: dr_pre, dz_pre, dn_pre, dghn
+    // ================================================================ members: cell backward of the own units, one wave per group
     if (!virt) {
-      if (wave == 0) {
-        const float* gp = a.GT[0] + (((size_t)p * G + g) * KG + cu) * 1024 + lane * 4;
+      f32x4 gr = z4, gz = z4, gn = z4, gg = z4;    // dr_pre, dz_pre, dn_pre, dghn
+      if (mygrp) {
+        const float* gp = a.GT[0] + (((size_t)p * G + gw) * KG + cu) * 1024 + lane * 4;
         const f32x4 r = ld4(gp), z = ld4(gp + 256), n = ld4(gp + 512), ghn = ld4(gp + 768);
-        const float* hh = a.HH[0] + (((size_t)p * G + g) * H + 16 * cu + 4 * q) * 16 + b;
+        const float* hh = a.HH[0] + (((size_t)p * G + gw) * H + 16 * cu + 4 * q) * 16 + b;
         f32x4 hp;
 #pragma unroll
         for (int j = 0; j < 4; ++j) hp[j] = hh[j * 16];
@@ -180,30 +219,29 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
           gr[j] = dr * r[j] * (1.0f - r[j]);
           dhz[j] = d * z[j];
         }
-        st4(dgl + lane * 4, gr); st4(dgl + 256 + lane * 4, gz); st4(dgl + 512 + lane * 4, gn); st4(dgl + 768 + lane * 4, gg);
-      }
-      __syncthreads();
-      if (wave < 4) {
-        // partial dtop of stack columns 16*wave..: the own 48 gate rows' share, B operand = own dgi blocks
-        f32x4 acc = z4;
-#pragma unroll
-        for (int piece = 0; piece < 3; ++piece) {
-          const f32x4 wv = ld4(wt_is + (size_t)(wave * 3 + piece) * 256 + lane * 4), x = ld4(dgl + piece * 256 + lane * 4);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], x[0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], x[1], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], x[2], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], x[3], acc, 0, 0, 0);
-        }
-        xst4(ptb, (unsigned)((cu * 4 + wave) * 256 + lane * 4) * 4u, acc);
-      } else if (wave < 7) {
         // dr | dz | dghn blocks of the own units for the other members' W_hh^T products
-        const int p3 = wave - 4;
-        xst4(dgw, (unsigned)((p3 * C + cu) * 256 + lane * 4) * 4u, ld4(dgl + (p3 == 2 ? 3 : p3) * 256 + lane * 4));
+        xst4(dgw, (unsigned)(((wave * 3 + 0) * C + cu) * 256 + lane * 4) * 4u, gr);
+        xst4(dgw, (unsigned)(((wave * 3 + 1) * C + cu) * 256 + lane * 4) * 4u, gz);
+        xst4(dgw, (unsigned)(((wave * 3 + 2) * C + cu) * 256 + lane * 4) * 4u, gg);
+        // partial dtop of the four 16-column tiles: the own 48 gate rows' share, B operand = own dgi blocks (registers)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          f32x4 acc = z4;
+          const f32x4 w0 = ld4(wt_is + (size_t)(t * 3 + 0) * 256 + lane * 4), w1 = ld4(wt_is + (size_t)(t * 3 + 1) * 256 + lane * 4),
+                      w2 = ld4(wt_is + (size_t)(t * 3 + 2) * 256 + lane * 4);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[c], gr[c], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[c], gz[c], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[c], gn[c], acc, 0, 0, 0);
+          }
+          xst4(ptb, (unsigned)(((wave * C + cu) * 4 + t) * 256 + lane * 4) * 4u, acc);
+        }
       }
       BC_ARRIVE();
-      if (wave == 0) {
+      if (mygrp) {
         // gate-gradient slab rows of the own units (A operand of the weight-gradient GEMM): off the chain
-        float* dg = a.DG[0] + (((size_t)p * G + g) * 4 * H + 16 * cu + 4 * q) * 16 + b;
+        float* dg = a.DG[0] + (((size_t)p * G + gw) * 4 * H + 16 * cu + 4 * q) * 16 + b;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           dg[(size_t)j * 16] = gr[j];
@@ -216,13 +254,12 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
     }
 
     // ================================================================ owners: per-sequence backward
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int s = cu + k * C;
-      if (k >= NOWN || s >= 16) break;
-      const int row = row0 + s;
+    for (int k = 0; k < nown; ++k) {
+      const int sg = cu + k * C;
+      const int r = sg >> 4, s = sg & 15, g = g0 + r;
+      const int row = row00 + sg;
       const bool rowok = row < B;
-      const float Rs = k ? R1 : R0;
+      const float Rs = own[k * 2];
       float* dsin = dsb + ((size_t)k * 2 + ((p + 1) & 1)) * DW;   // gradient w.r.t. S_p
       float* dsout = dsb + ((size_t)k * 2 + (p & 1)) * DW;        // gradient w.r.t. S_{p-1}
       // dlogits_{p-1} inputs and the old stack are requested first (plain loads: forward history)
@@ -241,7 +278,7 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
         // dtop of this sequence: sum of the C members' partials
         for (int t = tid; t < C * 16; t += BC_THREADS) {
           const int cm = t >> 4, tt = (t >> 2) & 3, kq = t & 3;
-          st4(red + cm * 64 + 16 * tt + 4 * kq, xld4(ptb, (unsigned)((cm * 4 + tt) * 256 + (s + 16 * kq) * 4) * 4u));
+          st4(red + cm * 64 + 16 * tt + 4 * kq, xld4(ptb, (unsigned)(((r * C + cm) * 4 + tt) * 256 + (s + 16 * kq) * 4) * 4u));
         }
         __syncthreads();
         if (tid < 64) {
@@ -285,123 +322,128 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
       }
       // ---- dlogits_{p-1} and the loss term
       if (tid < V) dxl[3 + W + tid] = (p >= 1) ? a.scale * Rs * (prv - ((tid == y) ? 1.0f : 0.0f)) : 0.0f;
-      if (tid == 0 && p >= 1) {
-        const float lp = a.LP[((size_t)(p - 1) * G + g) * 16 + s];
-        if (k) lossacc1 += Rs * lp; else lossacc0 += Rs * lp;
-      }
+      if (tid == 0 && p >= 1) own[k * 2 + 1] += Rs * a.LP[((size_t)(p - 1) * G + g) * 16 + s];
       __syncthreads();
       // ---- publish dx of this sequence (1-KB record: one 16-byte store per lane of wave 0) and its DX slab column
-      if (wave == 0) xst4(dxb, (unsigned)(s * 256 + lane * 4) * 4u, ld4(dxl + lane * 4));
+      if (wave == 0) xst4(dxb, (unsigned)(sg * 256 + lane * 4) * 4u, ld4(dxl + lane * 4));
       if (tid < NXT * 16) a.DX[((size_t)p * G + g) * NXT * 256 + (size_t)tid * 16 + s] = dxl[tid];
-      if (k + 1 < NOWN) __syncthreads();
+      if (k + 1 < nown) __syncthreads();
     }
     BC_ARRIVE();
-    // ---- under the wait of barrier B: W_hh^T [dr; dz; dghn] for the own units, K split over the waves
+    // ---- under the wait of barrier B: W_hh^T [dr; dz; dghn] of every group for the own units, K split over the waves
     if (!virt) {
-      f32x4 acc0 = z4, acc1 = z4;
-      constexpr int KPW = KG3 / 8;
+      for (int r = 0; r < NGc; ++r) {
+        float* redr = red + (size_t)(r & 1) * 8 * 256;
+        f32x4 xv[KPW];
 #pragma unroll
-      for (int i = 0; i < KPW; ++i) {
-        const int kgi = wave * KPW + i;
-        const int kc = kgi / 24, rem = kgi - kc * 24, piece = rem >> 3, kwv = rem & 7;
-        const int u = kwv * UPW + kc;
-        const f32x4 x = xld4(dgw, (unsigned)((piece * C + u) * 256 + lane * 4) * 4u);
-        const f32x4 wv = ld4(wt_hh + (size_t)kgi * 256 + lane * 4);
-        if (i & 1) {
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], x[0], acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], x[1], acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], x[2], acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], x[3], acc1, 0, 0, 0);
-        } else {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], x[0], acc0, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], x[1], acc0, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], x[2], acc0, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], x[3], acc0, 0, 0, 0);
+        for (int i = 0; i < KPW; ++i) {
+          const int kgi = wave * KPW + i;
+          const int kc = kgi / 24, rem = kgi - kc * 24, piece = rem >> 3, kwv = rem & 7;
+          const int u = kwv * UPW + kc;
+          xv[i] = xld4(dgw, (unsigned)(((r * 3 + piece) * C + u) * 256 + lane * 4) * 4u);
+        }
+        f32x4 acc0 = z4, acc1 = z4;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+          if (i & 1) {
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wthh[i][0], xv[i][0], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wthh[i][1], xv[i][1], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wthh[i][2], xv[i][2], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wthh[i][3], xv[i][3], acc1, 0, 0, 0);
+          } else {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wthh[i][0], xv[i][0], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wthh[i][1], xv[i][1], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wthh[i][2], xv[i][2], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wthh[i][3], xv[i][3], acc0, 0, 0, 0);
+          }
+        }
+        st4(redr + wave * 256 + lane * 4, acc0 + acc1);
+        __syncthreads();                         // partials of group r visible (the other buffer is read by wave r-1 only)
+        if (wave == r) {
+          f32x4 sum = z4;
+#pragma unroll
+          for (int wv = 0; wv < 8; ++wv) sum += ld4(redr + wv * 256 + lane * 4);
+          hhs = sum;
         }
       }
-      st4(red + wave * 256 + lane * 4, acc0 + acc1);
     }
-    if (!(ok = BC_WAIT())) break;                // B: dx of all 16 sequences visible
-    // ================================================================ members: the new carry of the own units
-    if (wave == 0) {
-      f32x4 acc0 = virt ? z4 : dhz, acc1 = z4;
-      if (!virt) {
+    if (!(ok = BC_WAIT())) break;                // B: dx of every sequence visible
+    // ================================================================ members: the new carry of the own units, one wave per group
+    if (mygrp) {
+      f32x4 acc0 = virt ? z4 : dhz + hhs, acc1 = z4;
+      for (int kg = 0; kg < NXT; kg += 2) {
+        const f32x4 x0 = xld4(dxb, (unsigned)((wave * 16 + b) * 256 + 16 * kg + 4 * q) * 4u);
+        const f32x4 w0 = ld4(wt_x + (size_t)kg * 256 + lane * 4);
+        f32x4 x1 = z4, w1 = z4;
+        if (kg + 1 < NXT) {
+          x1 = xld4(dxb, (unsigned)((wave * 16 + b) * 256 + 16 * (kg + 1) + 4 * q) * 4u);
+          w1 = ld4(wt_x + (size_t)(kg + 1) * 256 + lane * 4);
+        }
 #pragma unroll
-        for (int wv = 0; wv < 8; ++wv) acc1 += ld4(red + wv * 256 + lane * 4);
-      }
-      for (int kg = 0; kg < NXT; ++kg) {
-        const f32x4 x = xld4(dxb, (unsigned)(b * 256 + 16 * kg + 4 * q) * 4u);
-        const f32x4 wv = ld4(wt_x + (size_t)kg * 256 + lane * 4);
-        if (kg & 1) {
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], x[0], acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], x[1], acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], x[2], acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], x[3], acc1, 0, 0, 0);
-        } else {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], x[0], acc0, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], x[1], acc0, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], x[2], acc0, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], x[3], acc0, 0, 0, 0);
+        for (int c = 0; c < 4; ++c) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[c], x0[c], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[c], x1[c], acc1, 0, 0, 0);
         }
       }
       car = acc0 + acc1;
     }
-    __syncthreads();                             // red / dxl reusable
   }
 
   // ---------------------------------------------------------------- outputs
+  const float nanv = __int_as_float(0x7fc00000);
   if (!ok) {
     // gave up on a barrier: poison what the caller will look at
-    const float nanv = __int_as_float(0x7fc00000);
-    if (wave == 0 && row0 + b < B) st4(a.grad_h0 + (size_t)(row0 + b) * H + 16 * cu + 4 * q, (f32x4){nanv, nanv, nanv, nanv});
-    if (cu == 0 && tid == 0) a.LOSSP[g] = nanv;
+    if (mygrp && row00 + 16 * wave + b < B)
+      st4(a.grad_h0 + (size_t)(row00 + 16 * wave + b) * H + 16 * cu + 4 * q, (f32x4){nanv, nanv, nanv, nanv});
+    if (cu == 0 && tid < NGc) a.LOSSP[g0 + tid] = nanv;
     return;
   }
-  if (wave == 0 && row0 + b < B) st4(a.grad_h0 + (size_t)(row0 + b) * H + 16 * cu + 4 * q, car);
-  // loss partial of the row group: owners publish sum_p R * logp of their rows, member 0 adds them in row order
-  if (owner && wave == 0) {
-    xst1(lsb, (unsigned)(cu * 64 + lane) * 4u, lane == 0 ? lossacc0 : 0.0f);
-    if (NOWN > 1 && cu + C < 16) xst1(lsb, (unsigned)((cu + C) * 64 + lane) * 4u, lane == 0 ? lossacc1 : 0.0f);
-  }
+  if (mygrp && row00 + 16 * wave + b < B) st4(a.grad_h0 + (size_t)(row00 + 16 * wave + b) * H + 16 * cu + 4 * q, car);
+  // loss partial of every row group: owners publish sum_p R * logp of their rows, member 0 adds them in row order
+  __syncthreads();
+  for (int k = wave; k < nown; k += 8) xst1(lsb, (unsigned)((cu + k * C) * 64 + lane) * 4u, lane == 0 ? own[k * 2 + 1] : 0.0f);
   BC_ARRIVE();
   ok = BC_WAIT();
-  if (cu == 0 && tid == 0) {
+  if (cu == 0 && tid < NGc) {
     float sacc = 0.0f;
-    for (int r = 0; r < 16; ++r) sacc += xld1(lsb, (unsigned)(r * 64) * 4u);
-    a.LOSSP[g] = ok ? -a.scale * sacc : __int_as_float(0x7fc00000);
+    for (int r = 0; r < 16; ++r) sacc += xld1(lsb, (unsigned)((tid * 16 + r) * 64) * 4u);
+    a.LOSSP[g0 + tid] = ok ? -a.scale * sacc : nanv;
   }
 }
 
-size_t bwdc_lds_bytes(const BwdArgs* a) {
-  const int KG = a->H / 16, nown = (16 + KG - 1) / KG, KG3 = 3 * a->H / 16;
-  return ((size_t)KG3 * 256 + 12 * 256 + (size_t)a->NXT * 256 + 8 * 256 + 4 * 256 + 64 + 256 + 32 + (size_t)a->D * a->W +
-          (size_t)nown * 2 * a->D * a->W + 64) * sizeof(float);
+int bwdc_nown(const BwdArgs* a, int ng) { const int C = a->H / 16; return (16 * ng + C - 1) / C; }
+size_t bwdc_lds_bytes(const BwdArgs* a, int ng) {
+  return (size_t)bc_lds(a->NXT, bwdc_nown(a, ng), a->D * a->W).end * sizeof(float);
 }
 
 }  // namespace
 
-// Floats of the exchange region per launch (G clusters).
+// Floats of the exchange region per launch: NG row groups per cluster, ceil(G / NG) clusters.
 size_t pmg_bwdc_cx_floats(const PmgDims& d) {
-  const size_t C = d.H / 16;
-  return (size_t)d.G * ((size_t)2 * 3 * C * 256 + C * 4 * 256 + 16 * 256 + 16 * 64);
+  const size_t C = d.H / 16, ng = pmg_cluster_ng(d.G, d.H), ncl = (d.G + ng - 1) / ng;
+  return ncl * ng * ((size_t)2 * 3 * C * 256 + C * 4 * 256 + 16 * 256 + 16 * 64);
 }
 
 bool pmg_bwdc_applicable(const BwdArgs* a) {
   if (a->flags & PMG_FLAG_NO_CLUSTER) return false;
   if (a->L != 1 || a->H > 512 || a->NX > 256 || a->V > 512 || a->CX == nullptr) return false;
-  const int C = a->H / 16;
-  if (a->G > 8 * (32 / C)) return false;
+  const int ng = pmg_cluster_ng(a->G, a->H);
+  if (ng > PMG_CLUSTER_NG_MAX) return false;
   if (BC_THREADS / a->W < 1) return false;
-  return bwdc_lds_bytes(a) <= (size_t)160 * 1024;
+  return bwdc_lds_bytes(a, ng) <= (size_t)160 * 1024;
 }
 
-hipError_t pmg_launch_bwdc(const BwdArgs* a, hipStream_t st) {
+hipError_t pmg_launch_bwdc(const BwdArgs* a0, hipStream_t st) {
+  BwdArgs args = *a0;
+  const int ng = pmg_cluster_ng(a0->G, a0->H), ncl = (a0->G + ng - 1) / ng;
+  args.cluster_ng = ng;
+  const BwdArgs* a = &args;
   const int C = a->H / 16;
-  size_t lds = bwdc_lds_bytes(a);
+  size_t lds = bwdc_lds_bytes(a, ng);
   if (lds < (size_t)81 * 1024) lds = (size_t)81 * 1024;     // more than half a CU: one workgroup per CU
-  hipError_t e = hipMemsetAsync(a->CXS, 0, (size_t)32 * (1 + a->G) * sizeof(unsigned), st);
+  hipError_t e = hipMemsetAsync(a->CXS, 0, (size_t)32 * (1 + ncl) * sizeof(unsigned), st);
   if (e != hipSuccess) return e;
-  const int grid = 8 * C * ((a->G + 7) / 8);
+  const int grid = 8 * C * ((ncl + 7) / 8);
 #define BC_LAUNCH(HM_)                                                                                  \
   {                                                                                                     \
     static std::atomic<unsigned long long> done{0};                                                     \

@@ -494,18 +494,23 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
     FC_TICK(4)
     // ================================================================ members: gates of the own 16 units, group by group
     int allfin = 1;                                          // wave 1, decode: every sequence so far has finished
-    for (int r = 0; r < NGc; ++r) {
-      float* redr = red + (size_t)(r & 1) * 8 * 2 * 256;
-      f32x4 acc0 = z4, acc1 = z4;
-      // every exchanged operand of this wave is requested up front: one L2 round trip, not one per k group
-      const float4 xt = xld4(rec, (unsigned)((r * 16 + b) * 128 + 16 * kw + 4 * q) * 4u);       // stack-top k group kw
-      float4 xs[HM];
+    // every exchanged operand of a wave is requested up front: one L2 round trip per group, not one per k group.
+    // (Requesting them a group ahead was measured slower: the registers it keeps live across the reduction
+    // and the cell spill, and the reloads cost more than the round trip -- profiles/r03_cluster_groups.md.)
+    float4 xt, xs[HM];
+    float tkn = 0.0f;
+    int fl = 1;
+    auto load_ops = [&](const int r) {
+      xt = xld4(rec, (unsigned)((r * 16 + b) * 128 + 16 * kw + 4 * q) * 4u);                    // stack-top k group kw
 #pragma unroll
       for (int m = 0; m < HM; ++m) xs[m] = xld4(hin, (unsigned)((r * KG + kq0 + m) * 256 + lane * 4) * 4u);
-      float tkf = 0.0f;
-      if (wave == 0) tkf = xld1(rec, (unsigned)((r * 16 + b) * 128 + 64) * 4u);                  // token fed to row b at this step
-      int fl = 1;
+      if (wave == 0) tkn = xld1(rec, (unsigned)((r * 16 + b) * 128 + 64) * 4u);                 // token fed to row b at this step
       if (decode && wave == 1 && lane < 16) fl = __float_as_int(xld1(rec, (unsigned)((r * 16 + lane) * 128 + 65) * 4u));
+    };
+    for (int r = 0; r < NGc; ++r) {
+      load_ops(r);
+      float* redr = red + (size_t)(r & 1) * 8 * 2 * 256;
+      f32x4 acc0 = z4, acc1 = z4;
       if (wave < 4) {
 #pragma unroll
         for (int m = 0; m < HM; ++m) {
@@ -543,10 +548,11 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis0[2], xt.z, acc0, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis0[3], xt.w, acc0, 0, 0, 0);
       }
+      const float tkf = tkn;
+      // finished flags of the group's 16 sequences: ONE load per lane of wave 1, combined by a ballot
+      if (decode && wave == 1) { allfin = (allfin && __all(fl != 0)) ? 1 : 0; fl = 1; }
       st4(redr + (size_t)(wave * 2 + 0) * 256 + lane * 4, acc0);
       st4(redr + (size_t)(wave * 2 + 1) * 256 + lane * 4, acc1);
-      // finished flags of the group's 16 sequences: ONE load per lane of wave 1, combined by a ballot
-      if (decode && wave == 1) allfin = (allfin && __all(fl != 0)) ? 1 : 0;
       __syncthreads();                            // partials of group r visible (the other buffer is being read by nobody)
       if (wave == 0) {
         f32x4 vr = z4, vz = z4, vi = z4, vh = z4;

@@ -102,7 +102,7 @@ struct FwdArgs {
 hipError_t pmg_launch_fwd(const FwdArgs* a, hipStream_t st);
 // Clustered kernels: a cluster is H/16 workgroups, at most 8 * floor(32 / (H/16)) clusters are resident
 // at once; more row groups than that are served NG per cluster.
-#define PMG_CLUSTER_NG_MAX 16
+#define PMG_CLUSTER_NG_MAX 8
 static inline int pmg_cluster_ng(int G, int H) {
   const int ncl = 8 * (32 / (H / 16));
   return (G + ncl - 1) / ncl;
@@ -138,6 +138,7 @@ struct BwdArgs {
   float* LOSSP;               // [G] loss partials
   // clustered BPTT (pmg_bwdc.hip): exchange buffers, counters, caller's flags
   float* CX; unsigned* CXS; uint32_t flags;
+  int cluster_ng;             // set by pmg_launch_bwdc: row groups per cluster
 };
 
 hipError_t pmg_launch_bwd(const BwdArgs* a, hipStream_t st);
