@@ -61,6 +61,7 @@ static void make_layout(const PmgDims& d, int mode, PmgLayout* L) {
       const size_t f = pmg_fwdc_cx_floats(d), b = pmg_bwdc_cx_floats(d);
       L->CX = take(f > b ? f : b);
       L->CXS = take(pmg_fwdc_sync_words(d));
+      L->LAYW = take(64);
     }
     L->SB = take(T * G * (size_t)d.SW);
     for (int l = 0; l < d.L; ++l) {
@@ -218,6 +219,7 @@ static void fill_fwd_common(FwdArgs* a, const PmgDims& d, const PmgLayout& lay, 
     a->CX = base + lay.CX;
     a->CXS = reinterpret_cast<unsigned*>(base + lay.CXS);
   }
+  if (lay.LAYW) a->LAYW = reinterpret_cast<unsigned*>(base + lay.LAYW);
 }
 
 extern "C" int pmg_uses_cluster(const pmg_shape* s, int mode, uint32_t flags) {
@@ -434,6 +436,7 @@ extern "C" int pmg_reinforce_bptt(const pmg_shape* s, const pmg_weights* w, cons
     a.CX = base + lay.CX;
     a.CXS = reinterpret_cast<unsigned*>(base + lay.CXS);
   }
+  if (lay.LAYW) a.LAYW = reinterpret_cast<const unsigned*>(base + lay.LAYW);
   HIPCHK(pmg_launch_bwd(&a, st));
   return PMG_OK;
 }

@@ -209,6 +209,17 @@ __global__ __launch_bounds__(HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS
 
   constexpr int NTHR = HELP ? PMG_THREADS + PMG_HELP_THREADS : PMG_THREADS;
   const bool helper = HELP && wave >= PMG_WAVES;  // wave-uniform
+  if (a.LAYW != nullptr && *a.LAYW != 0u) {
+    // the clustered forward left the history in the per-sequence layout (FwdArgs::LAYW) and this launch was
+    // told PMG_FLAG_NO_CLUSTER: no plausible-looking numbers out of a workspace this kernel cannot read
+    const float nanv = __int_as_float(0x7fc00000);
+    for (int i = tid; i < 16 * L * H; i += NTHR) {
+      const int r = i / (L * H), rem = i - r * (L * H);
+      if (row0 + r < B) a.grad_h0[((size_t)(rem / H) * B + row0 + r) * H + rem % H] = nanv;
+    }
+    if (tid == 0) a.LOSSP[g] = nanv;
+    return;
+  }
 #if PMG_HELP_PRIO
   // a helper shares its SIMD with two MFMA waves that always have an instruction ready; without
   // priority its few VALU / LDS / memory instructions wait for gaps in their issue

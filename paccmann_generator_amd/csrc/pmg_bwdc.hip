@@ -79,18 +79,20 @@ __device__ __forceinline__ float wave_sum(float x) {
 }
 
 // LDS map (float offsets), shared by the kernel and the host-side size check.
-struct BcLds { unsigned wt_is, wt_x, red, dtl, dxl, r3, own, sprev, dsb, misc, end; };
+#define BC_HIST 336   // floats of forward history per owned sequence: PV[64] | push, pop, no-op, logp, token | .. | PR[V] from 72
+struct BcLds { unsigned wt_is, wt_x, red, own, dtls, r3s, dxls, hist, sprevs, dsb, misc, end; };
 __host__ __device__ inline BcLds bc_lds(const int NXT, const int NOWN, const int DW) {
   BcLds o;
   unsigned p = 0;
   o.wt_is = p; p += 12 * 256;               // [4][3][64][4]  own gate rows' part of W_ih[:, E:]^T
   o.wt_x = p; p += (unsigned)NXT * 256;     // [NXT][64][4]   rows 16cu.. of [ctrl; push; out]^T
-  o.red = p; p += 2 * 8 * 256;              // [2][8][256] K-split partials (double-buffered over the groups); owners: [C][64] dtop partials
-  o.dtl = p; p += 64;                       // [64] dtop of the sequence being served
-  o.dxl = p; p += 256;                      // [256] dx of the sequence being served
-  o.r3 = p; p += 32;                        // [8][4] control-gradient partials per wave
-  o.own = p; p += (unsigned)NOWN * 2;       // [NOWN][2] reward | sum_p R * logp of the owned sequences
-  o.sprev = p; p += (unsigned)DW;           // [D*W] S_{p-1} of the sequence being served
+  o.red = p; p += 2 * 8 * 256;              // [2][8][256] K-split partials, double-buffered over the groups
+  o.own = p; p += (unsigned)NOWN * 4;       // [NOWN][4] reward | sum_p R * logp of the owned sequences
+  o.dtls = p; p += (unsigned)NOWN * 64;     // [NOWN][64] dtop
+  o.r3s = p; p += (unsigned)NOWN * 32;      // [NOWN][8][4] control-gradient partials per wave
+  o.dxls = p; p += (unsigned)NOWN * 256;    // [NOWN][256] dx
+  o.hist = p; p += (unsigned)NOWN * BC_HIST;   // forward history of the step, fetched under barrier A
+  o.sprevs = p; p += (unsigned)NOWN * DW;   // [NOWN][D*W] S_{p-1}, fetched under barrier A
   o.dsb = p; p += (unsigned)NOWN * 2 * DW;  // [NOWN][2][D*W] stack gradient ping-pong
   o.misc = p; p += 64;
   o.end = p;
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
   const int nown = (cu < NS) ? (NS - cu + C - 1) / C : 0;
   const int row00 = g0 * PMG_ROWS;
   const int DW = D * W;
+  const bool ht = a.LAYW != nullptr && *a.LAYW != 0u;   // history per sequence (FwdArgs::LAYW), as the clustered forward left it
   const bool mygrp = wave < NGc;                 // this wave carries group r = wave of the own units
   const int gw = g0 + wave;
 
@@ -133,11 +136,12 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
   float* wt_is = fs + lo.wt_is;
   float* wt_x = fs + lo.wt_x;
   float* red = fs + lo.red;
-  float* dtl = fs + lo.dtl;
-  float* dxl = fs + lo.dxl;
-  float* r3 = fs + lo.r3;
   float* own = fs + lo.own;
-  float* sprev = fs + lo.sprev;
+  float* dtls = fs + lo.dtls;
+  float* r3s = fs + lo.r3s;
+  float* dxls = fs + lo.dxls;
+  float* hist = fs + lo.hist;
+  float* sprevs = fs + lo.sprevs;
   float* dsb = fs + lo.dsb;
   int* misc = reinterpret_cast<int*>(fs + lo.misc);
 
@@ -157,6 +161,15 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
   unsigned bars = 0;
 #define BC_ARRIVE() (++bars, cluster_arrive(ctr))
 #define BC_WAIT() cluster_wait(ctr, (unsigned)C * bars, status, misc)
+#ifdef PMG_PROFILE
+  // -DPMG_PROFILE build + PMG_DEBUG bit 0x8000: per-phase cycle counters of member 0 of cluster 0
+  const bool prof = (a.dbg & 0x8000) != 0 && cl == 0 && cu == 0;
+  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#define BC_TICK(k) if (prof) { const long long tn_ = (long long)__builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; }
+#else
+#define BC_TICK(k)
+#endif
 
   // ---- resident transposed weights out of the packs.  W_hh^T rows 16cu..: [KG3][64][4] in chunk order;
   // wave w keeps reduction groups w*KPW .. w*KPW+KPW-1 in registers
@@ -177,12 +190,12 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
     for (int i = tid * 4; i < NXT * 256; i += BC_THREADS * 4) st4(wt_x + i, ld4(srcx + i));
   }
   for (int i = tid; i < NOWN * 2 * DW; i += BC_THREADS) dsb[i] = 0.0f;
-  for (int i = tid; i < 256; i += BC_THREADS) dxl[i] = 0.0f;
+  for (int i = tid; i < NOWN * 256; i += BC_THREADS) dxls[i] = 0.0f;
   if (tid < 64) misc[tid] = 0;
   if (tid < nown) {
     const int row = row00 + cu + tid * C;
-    own[tid * 2] = (row < B) ? a.reward[row] : 0.0f;
-    own[tid * 2 + 1] = 0.0f;
+    own[tid * 4] = (row < B) ? a.reward[row] : 0.0f;
+    own[tid * 4 + 1] = 0.0f;
   }
   __syncthreads();
 
@@ -193,6 +206,69 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
   f32x4 dhz = z4;                       // wave r: z * dh of this step
   f32x4 hhs = z4;                       // wave r: W_hh^T [dr; dz; dghn] of this step
   bool ok = true;
+  // Forward history of step p for every owned sequence -> LDS: S_{p-1}, push values, controls, log-prob, target
+  // token, probabilities.  Plain loads of what the forward wrote long ago; issued under the wait of barrier A.
+  auto fetch_history = [&](const int p) {
+    const bool virt = (p == N);
+    if (!virt) {
+      // S_{p-1} of every owned sequence: rows <= min(p-1, N-p, D-1) hold data (pmg_fwd.hip "live rows"), the rest
+      // is zero.  Eight loads in flight per thread ACROSS the owned sequences: one memory latency, not one per sequence.
+      const int s_hi = (p == 0) ? -1 : min(min(p - 1, N - p), D - 1);
+      const int rpt = (D + SDS - 1) / SDS, M = nown * rpt;
+      for (int m0 = 0; m0 < M; m0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int m = m0 + u, k = m / rpt, d = sd0 + (m - k * rpt) * SDS;
+          const int sg = cu + k * C, s = sg & 15, g = g0 + (sg >> 4);
+          v[u] = 0.0f;
+          if (m < M && sw < W && d <= s_hi) {
+            const float* Sp = a.SB + ((size_t)p * G + g) * a.SW;
+            v[u] = Sp[ht ? (size_t)s * DW + d * W + sw : (size_t)(d * W + sw) * 16 + s];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int m = m0 + u, k = m / rpt, d = sd0 + (m - k * rpt) * SDS;
+          if (m < M && sw < W && d < D) sprevs[(size_t)k * DW + d * W + sw] = v[u];
+        }
+      }
+    }
+    // push values, controls, log-prob, target token (one thread each) and probabilities: four sequences per round
+    for (int k0 = 0; k0 < nown; k0 += 4) {
+      float v1[4], v2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u;
+        const int sg = cu + k * C, s = sg & 15, g = g0 + (sg >> 4), row = row00 + sg;
+        v1[u] = 0.0f; v2[u] = 0.0f;
+        if (k < nown) {
+          if (!virt) {
+            if (tid < W) v1[u] = a.PV[((size_t)p * G + g) * 1024 + (ht ? s * 64 + tid : tid * 16 + s)];
+            else if (tid >= 64 && tid < 67) v1[u] = a.CT[((size_t)p * G + g) * 64 + (tid - 64) * 16 + s];
+          }
+          if (p >= 1) {
+            if (tid == 67) v1[u] = a.LP[((size_t)(p - 1) * G + g) * 16 + s];
+            if (tid == 68) v1[u] = __int_as_float((row < B) ? min(max((int)a.tokens[(size_t)p * B + row], 0), V - 1) : 0);
+            if (tid >= 128 && tid < 128 + V)
+              v2[u] = a.PR[((size_t)(p - 1) * G + g) * a.VP * 16 + (ht ? s * a.VP + tid - 128 : (tid - 128) * 16 + s)];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u;
+        if (k < nown) {
+          float* hk = hist + k * BC_HIST;
+          if (!virt && (tid < W || (tid >= 64 && tid < 67))) hk[tid] = v1[u];
+          if (p >= 1) {
+            if (tid == 67 || tid == 68) hk[tid] = v1[u];
+            if (tid >= 128 && tid < 128 + V) hk[72 + tid - 128] = v2[u];
+          }
+        }
+      }
+    }
+  };
 
   for (int p = N; p >= 0 && ok; --p) {
     const bool virt = (p == N);
@@ -238,6 +314,7 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
           xst4(ptb, (unsigned)(((wave * C + cu) * 4 + t) * 256 + lane * 4) * 4u, acc);
         }
       }
+      BC_TICK(0)
       BC_ARRIVE();
       if (mygrp) {
         // gate-gradient slab rows of the own units (A operand of the weight-gradient GEMM): off the chain
@@ -250,51 +327,41 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
           dg[((size_t)3 * H + j) * 16] = gg[j];
         }
       }
+      fetch_history(p);
       if (!(ok = BC_WAIT())) break;              // A: every member's dgate blocks and dtop partials visible
+      BC_TICK(1)
     }
 
     // ================================================================ owners: per-sequence backward
-    for (int k = 0; k < nown; ++k) {
-      const int sg = cu + k * C;
-      const int r = sg >> 4, s = sg & 15, g = g0 + r;
-      const int row = row00 + sg;
-      const bool rowok = row < B;
-      const float Rs = own[k * 2];
-      float* dsin = dsb + ((size_t)k * 2 + ((p + 1) & 1)) * DW;   // gradient w.r.t. S_p
-      float* dsout = dsb + ((size_t)k * 2 + (p & 1)) * DW;        // gradient w.r.t. S_{p-1}
-      // dlogits_{p-1} inputs and the old stack are requested first (plain loads: forward history)
-      float prv = 0.0f;
-      int y = 0;
-      if (p >= 1) {
-        y = rowok ? min(max((int)a.tokens[(size_t)p * B + row], 0), V - 1) : 0;
-        if (tid < V) prv = a.PR[(((size_t)(p - 1) * G + g) * a.VP + tid) * 16 + s];
+    if (virt) { fetch_history(p); __syncthreads(); }
+    // (i) dtop of every owned sequence: wave k sums the C members' partials of sequence k (lane = stack column)
+    if (!virt)
+      for (int k = wave; k < nown; k += 8) {
+        const int sg = cu + k * C, r = sg >> 4, s = sg & 15;
+        const int tt = lane >> 4, kq = (lane >> 2) & 3, j = lane & 3;
+        float v[C];
+#pragma unroll
+        for (int cm = 0; cm < C; ++cm) v[cm] = xld1(ptb, (unsigned)((((r * C + cm) * 4 + tt) * 256 + (s + 16 * kq) * 4 + j)) * 4u);
+        float acc = 0.0f;
+#pragma unroll
+        for (int cm = 0; cm < C; ++cm) acc += v[cm];
+        dtls[k * 64 + lane] = acc;
       }
-      if (!virt) {
-        // S_{p-1}: rows <= min(p-1, N-p, D-1) hold data (pmg_fwd.hip "live rows"), the rest is zero
-        const int s_hi = (p == 0) ? -1 : min(min(p - 1, N - p), D - 1);
-        const float* Sp = a.SB + ((size_t)p * G + g) * a.SW;
-        for (int d = sd0; d < D; d += SDS)
-          if (sw < W) sprev[d * W + sw] = (d <= s_hi) ? Sp[(size_t)(d * W + sw) * 16 + s] : 0.0f;
-        // dtop of this sequence: sum of the C members' partials
-        for (int t = tid; t < C * 16; t += BC_THREADS) {
-          const int cm = t >> 4, tt = (t >> 2) & 3, kq = t & 3;
-          st4(red + cm * 64 + 16 * tt + 4 * kq, xld4(ptb, (unsigned)(((r * C + cm) * 4 + tt) * 256 + (s + 16 * kq) * 4) * 4u));
-        }
-        __syncthreads();
-        if (tid < 64) {
-          float acc = 0.0f;
-          for (int cm = 0; cm < C; ++cm) acc += red[cm * 64 + tid];
-          dtl[tid] = acc;
-        }
-        const float apush = a.CT[((size_t)p * G + g) * 64 + s], apop = a.CT[((size_t)p * G + g) * 64 + 16 + s],
-                    anoop = a.CT[((size_t)p * G + g) * 64 + 32 + s];
-        __syncthreads();
-        // ---- stack backward: G(d) = dS_p[d] (+ dtop at row 0); rows beyond N-p carry no gradient
+    __syncthreads();
+    // (ii) stack backward of every owned sequence (all threads, LDS only): G(d) = dS_p[d] (+ dtop at row 0);
+    // rows beyond N-p carry no gradient
+    if (!virt)
+      for (int k = 0; k < nown; ++k) {
+        const float* hk = hist + k * BC_HIST;
+        const float* sprev = sprevs + (size_t)k * DW;
+        const float* dsin = dsb + ((size_t)k * 2 + ((p + 1) & 1)) * DW;   // gradient w.r.t. S_p
+        float* dsout = dsb + ((size_t)k * 2 + (p & 1)) * DW;              // gradient w.r.t. S_{p-1}
+        const float apush = hk[64], apop = hk[65], anoop = hk[66];
         const int dlim = min(N - p, D - 1);
         float sn = 0.0f, sp = 0.0f, sq = 0.0f;
         if (sw < W) {
-          const float pv = a.PV[((size_t)p * G + g) * 1024 + sw * 16 + s];
-          const float dt = dtl[sw];
+          const float pv = hk[sw];
+          const float dt = dtls[k * 64 + sw];
           for (int d = sd0; d <= dlim; d += SDS) {
             const int idx = d * W + sw;
             const float gc = dsin[idx] + (d == 0 ? dt : 0.0f);
@@ -305,36 +372,53 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
             const float sdn = (d + 1 < D) ? sprev[idx + W] : 0.0f;
             sn += gc * sc; sp += gc * su; sq += gc * sdn;
             dsout[idx] = anoop * gc + apush * gx + apop * gm;
-            if (d == 0) dxl[3 + sw] = apush * gc * (1.0f - pv * pv);
+            if (d == 0) dxls[k * 256 + 3 + sw] = apush * gc * (1.0f - pv * pv);
           }
         }
         sn = wave_sum(sn); sp = wave_sum(sp); sq = wave_sum(sq);
-        if (lane == 0) { r3[wave * 4] = sp; r3[wave * 4 + 1] = sq; r3[wave * 4 + 2] = sn; }
-        __syncthreads();
-        if (tid == 0) {
-          float dpu = 0.f, dpo = 0.f, dno = 0.f;
-          for (int wv = 0; wv < 8; ++wv) { dpu += r3[wv * 4]; dpo += r3[wv * 4 + 1]; dno += r3[wv * 4 + 2]; }
-          const float sm = apush * dpu + apop * dpo + anoop * dno;
-          dxl[0] = apush * (dpu - sm); dxl[1] = apop * (dpo - sm); dxl[2] = anoop * (dno - sm);
-        }
-      } else {
-        if (tid < 3 + W) dxl[tid] = 0.0f;
+        if (lane == 0) { r3s[(k * 8 + wave) * 4] = sp; r3s[(k * 8 + wave) * 4 + 1] = sq; r3s[(k * 8 + wave) * 4 + 2] = sn; }
       }
-      // ---- dlogits_{p-1} and the loss term
-      if (tid < V) dxl[3 + W + tid] = (p >= 1) ? a.scale * Rs * (prv - ((tid == y) ? 1.0f : 0.0f)) : 0.0f;
-      if (tid == 0 && p >= 1) own[k * 2 + 1] += Rs * a.LP[((size_t)(p - 1) * G + g) * 16 + s];
-      __syncthreads();
-      // ---- publish dx of this sequence (1-KB record: one 16-byte store per lane of wave 0) and its DX slab column
-      if (wave == 0) xst4(dxb, (unsigned)(sg * 256 + lane * 4) * 4u, ld4(dxl + lane * 4));
-      if (tid < NXT * 16) a.DX[((size_t)p * G + g) * NXT * 256 + (size_t)tid * 16 + s] = dxl[tid];
-      if (k + 1 < nown) __syncthreads();
+    __syncthreads();
+    // (iii) control gradients (thread k), dlogits_{p-1} and the loss term of every owned sequence
+    if (tid < nown) {
+      const int k = tid;
+      const float* hk = hist + k * BC_HIST;
+      if (!virt) {
+        const float apush = hk[64], apop = hk[65], anoop = hk[66];
+        float dpu = 0.f, dpo = 0.f, dno = 0.f;
+        for (int wv = 0; wv < 8; ++wv) { dpu += r3s[(k * 8 + wv) * 4]; dpo += r3s[(k * 8 + wv) * 4 + 1]; dno += r3s[(k * 8 + wv) * 4 + 2]; }
+        const float sm = apush * dpu + apop * dpo + anoop * dno;
+        dxls[k * 256] = apush * (dpu - sm); dxls[k * 256 + 1] = apop * (dpo - sm); dxls[k * 256 + 2] = anoop * (dno - sm);
+      } else {
+        dxls[k * 256] = 0.0f; dxls[k * 256 + 1] = 0.0f; dxls[k * 256 + 2] = 0.0f;
+      }
+      if (p >= 1) own[k * 4 + 1] += own[k * 4] * hk[67];
     }
+    for (int t = tid; t < nown * 256; t += BC_THREADS) {
+      const int k = t >> 8, v = t & 255;
+      const float* hk = hist + k * BC_HIST;
+      if (v < V) {
+        const int y = __float_as_int(hk[68]);
+        dxls[k * 256 + 3 + W + v] = (p >= 1) ? a.scale * own[k * 4] * (hk[72 + v] - ((v == y) ? 1.0f : 0.0f)) : 0.0f;
+      }
+      if (virt && v < W) dxls[k * 256 + 3 + v] = 0.0f;
+    }
+    __syncthreads();
+    // (iv) publish dx of every owned sequence (1-KB record: one 16-byte store per lane) and its DX slab column: wave k
+    for (int k = wave; k < nown; k += 8) {
+      const int sg = cu + k * C, s = sg & 15, g = g0 + (sg >> 4);
+      xst4(dxb, (unsigned)(sg * 256 + lane * 4) * 4u, ld4(dxls + k * 256 + lane * 4));
+      float* dxg = a.DX + ((size_t)p * G + g) * NXT * 256 + s;
+      for (int idx = lane; idx < NXT * 16; idx += 64) dxg[(size_t)idx * 16] = dxls[k * 256 + idx];
+    }
+    BC_TICK(2)
     BC_ARRIVE();
     // ---- under the wait of barrier B: W_hh^T [dr; dz; dghn] of every group for the own units, K split over the waves
     if (!virt) {
-      for (int r = 0; r < NGc; ++r) {
-        float* redr = red + (size_t)(r & 1) * 8 * 256;
-        f32x4 xv[KPW];
+      // the dgate blocks of group r+1 are requested as soon as the products of group r have consumed the registers:
+      // they land under its reduction
+      f32x4 xv[KPW];
+      auto load_dg = [&](const int r) {
 #pragma unroll
         for (int i = 0; i < KPW; ++i) {
           const int kgi = wave * KPW + i;
@@ -342,6 +426,10 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
           const int u = kwv * UPW + kc;
           xv[i] = xld4(dgw, (unsigned)(((r * 3 + piece) * C + u) * 256 + lane * 4) * 4u);
         }
+      };
+      load_dg(0);
+      for (int r = 0; r < NGc; ++r) {
+        float* redr = red + (size_t)(r & 1) * 8 * 256;
         f32x4 acc0 = z4, acc1 = z4;
 #pragma unroll
         for (int i = 0; i < KPW; ++i) {
@@ -357,6 +445,9 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wthh[i][3], xv[i][3], acc0, 0, 0, 0);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (r + 1 < NGc) load_dg(r + 1);
+        __builtin_amdgcn_sched_barrier(0);
         st4(redr + wave * 256 + lane * 4, acc0 + acc1);
         __syncthreads();                         // partials of group r visible (the other buffer is read by wave r-1 only)
         if (wave == r) {
@@ -367,7 +458,9 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
         }
       }
     }
+    BC_TICK(3)
     if (!(ok = BC_WAIT())) break;                // B: dx of every sequence visible
+    BC_TICK(4)
     // ================================================================ members: the new carry of the own units, one wave per group
     if (mygrp) {
       f32x4 acc0 = virt ? z4 : dhz + hhs, acc1 = z4;
@@ -387,7 +480,13 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
       }
       car = acc0 + acc1;
     }
+    BC_TICK(5)
   }
+#ifdef PMG_PROFILE
+  if (prof && tid == 0)
+    printf("bwdc member 0 cycles: cell+dtop %lld barrierA %lld owners %lld Whh^T product %lld barrierB %lld carry %lld\n", tph[0], tph[1], tph[2],
+           tph[3], tph[4], tph[5]);
+#endif
 
   // ---------------------------------------------------------------- outputs
   const float nanv = __int_as_float(0x7fc00000);
@@ -401,7 +500,7 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
   if (mygrp && row00 + 16 * wave + b < B) st4(a.grad_h0 + (size_t)(row00 + 16 * wave + b) * H + 16 * cu + 4 * q, car);
   // loss partial of every row group: owners publish sum_p R * logp of their rows, member 0 adds them in row order
   __syncthreads();
-  for (int k = wave; k < nown; k += 8) xst1(lsb, (unsigned)((cu + k * C) * 64 + lane) * 4u, lane == 0 ? own[k * 2 + 1] : 0.0f);
+  for (int k = wave; k < nown; k += 8) xst1(lsb, (unsigned)((cu + k * C) * 64 + lane) * 4u, lane == 0 ? own[k * 4 + 1] : 0.0f);
   BC_ARRIVE();
   ok = BC_WAIT();
   if (cu == 0 && tid < NGc) {
@@ -424,13 +523,19 @@ size_t pmg_bwdc_cx_floats(const PmgDims& d) {
   return ncl * ng * ((size_t)2 * 3 * C * 256 + C * 4 * 256 + 16 * 256 + 16 * 64);
 }
 
-bool pmg_bwdc_applicable(const BwdArgs* a) {
-  if (a->flags & PMG_FLAG_NO_CLUSTER) return false;
-  if (a->L != 1 || a->H > 512 || a->NX > 256 || a->V > 512 || a->CX == nullptr) return false;
-  const int ng = pmg_cluster_ng(a->G, a->H);
+bool pmg_bwdc_shape_ok(int H, int L, int NX, int NXT, int V, int W, int D, int G) {
+  if (L != 1 || H > 512 || NX > 256 || V > 264) return false;
+  const int ng = pmg_cluster_ng(G, H);
   if (ng > PMG_CLUSTER_NG_MAX) return false;
-  if (BC_THREADS / a->W < 1) return false;
-  return bwdc_lds_bytes(a, ng) <= (size_t)160 * 1024;
+  if (BC_THREADS / W < 1) return false;
+  BwdArgs t;
+  t.H = H; t.NXT = NXT; t.D = D; t.W = W;
+  return bwdc_lds_bytes(&t, ng) <= (size_t)160 * 1024;
+}
+
+bool pmg_bwdc_applicable(const BwdArgs* a) {
+  if ((a->flags & PMG_FLAG_NO_CLUSTER) || a->CX == nullptr) return false;
+  return pmg_bwdc_shape_ok(a->H, a->L, a->NX, a->NXT, a->V, a->W, a->D, a->G);
 }
 
 hipError_t pmg_launch_bwdc(const BwdArgs* a0, hipStream_t st) {

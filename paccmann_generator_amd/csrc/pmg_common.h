@@ -109,7 +109,7 @@ struct PmgLayout {
   size_t DHC;                 // [G][L][H*16] hidden-gradient carry
   size_t WG;                  // weight-gradient accumulators (packed "natural" matrices)
   size_t WGP;                 // split-K partials
-  size_t CX, CXS;             // clustered forward: exchange buffers, barrier counters (0: none)
+  size_t CX, CXS, LAYW;             // clustered forward: exchange buffers, barrier counters (0: none)
   size_t pack_end;            // end of the packed-weight region (covered by one buffer resource)
   size_t total;               // floats
 };

@@ -969,6 +969,10 @@ static hipError_t launch_fwd_h(const FwdArgs* a, hipStream_t st) {
 hipError_t pmg_launch_fwd(const FwdArgs* a, hipStream_t st) {
   // small batches: the hidden-partitioned form (a cluster of H/16 CUs per 16 sequences), same results
   if (pmg_fwdc_applicable(a)) return pmg_launch_fwdc(a, st);
+  if (a->mode == PMG_FWD_TEACHER && a->LAYW != nullptr) {   // history in the row-group-interleaved layout
+    const hipError_t e = hipMemsetAsync(a->LAYW, 0, sizeof(unsigned), st);
+    if (e != hipSuccess) return e;
+  }
   switch (a->H) {
     case 128: return launch_fwd_h<8, 1, 1>(a, st);
     case 256: return launch_fwd_h<8, 2, 2>(a, st);

@@ -176,6 +176,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
   int* misc = reinterpret_cast<int*>(fs + lo.misc);
   float* gtl = fs + lo.gtl;
   const bool gt_lds = a.cluster_gtab_lds != 0;
+  const bool ht = a.cluster_hist_t != 0;         // stack / push / probability history per sequence (FwdArgs::LAYW)
 
   // ---- exchange buffers of this cluster: two hidden-state buffers [NG][KG][64][4], records [16 NG][128]
   const size_t hbf = (size_t)NG * H * 16;
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
           float* pr = a.PR + ((size_t)(i - 1) * G + g) * a.VP * 16;
           const float inv = __builtin_amdgcn_rcpf(total);
 #pragma unroll 2
-          for (int v = l5; v < V; v += 32) pr[v * 16 + s] = __expf(lg[v] - m) * inv;
+          for (int v = l5; v < V; v += 32) pr[ht ? s * a.VP + v : v * 16 + s] = __expf(lg[v] - m) * inv;
         } else {
           bool fin = osi[k * 8 + 5] != 0;
           const bool greedy = !(a.temperature > 0.0f);
@@ -472,14 +473,14 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
           const float nw = anoop * sold[idx] + apush * sold[idx - W] + apop * nxt;
           snew[idx] = nw;
           // history the BPTT reads: only rows that can still reach a stack top (pmg_fwd.hip, "live rows")
-          if (teacher && d <= N - 1 - i) a.SB[((size_t)(i + 1) * G + g) * a.SW + (size_t)idx * 16 + s] = nw;
+          if (teacher && d <= N - 1 - i) a.SB[((size_t)(i + 1) * G + g) * a.SW + (ht ? (size_t)s * DW + idx : (size_t)idx * 16 + s)] = nw;
         }
       }
       if (teacher) {
         if (wave == 0 && lane < W) {
           const float pv = ptv[k * 128 + lane], top = ptv[k * 128 + 64 + lane];
-          a.SB[((size_t)(i + 1) * G + g) * a.SW + (size_t)lane * 16 + s] = top;
-          a.PV[((size_t)i * G + g) * 1024 + lane * 16 + s] = pv;
+          a.SB[((size_t)(i + 1) * G + g) * a.SW + (ht ? (size_t)s * DW + lane : (size_t)lane * 16 + s)] = top;
+          a.PV[((size_t)i * G + g) * 1024 + (ht ? s * 64 + lane : lane * 16 + s)] = pv;
           a.TP[((size_t)i * G + g) * 2048 + lane * 16 + s] = top;
         }
         if (tid >= 128 && tid < 131)
@@ -696,6 +697,8 @@ hipError_t pmg_launch_fwdc(const FwdArgs* a0, hipStream_t st) {
   const int ng = pmg_cluster_ng(a0->G, a0->H), ncl = (a0->G + ng - 1) / ng;
   args.cluster_ng = ng;
   args.cluster_gtab_lds = fwdc_gtab_fits(a0, ng) ? 1 : 0;
+  args.cluster_hist_t = (a0->mode == PMG_FWD_TEACHER && a0->LAYW != nullptr &&
+                         pmg_bwdc_shape_ok(a0->H, a0->L, a0->NX, a0->NXT, a0->V, a0->W, a0->D, a0->G)) ? 1 : 0;
   const FwdArgs* a = &args;
   const int C = a->H / 16;
   size_t lds = fwdc_lds_bytes(a, ng);
@@ -703,6 +706,10 @@ hipError_t pmg_launch_fwdc(const FwdArgs* a0, hipStream_t st) {
   // counters and the status word start at zero (stream-ordered; 128 B per counter)
   hipError_t e = hipMemsetAsync(a->CXS, 0, (size_t)32 * (1 + ncl) * sizeof(unsigned), st);
   if (e != hipSuccess) return e;
+  if (a->mode == PMG_FWD_TEACHER && a->LAYW != nullptr) {
+    e = hipMemsetAsync(a->LAYW, a->cluster_hist_t ? 1 : 0, sizeof(unsigned), st);
+    if (e != hipSuccess) return e;
+  }
   const int grid = 8 * C * ((ncl + 7) / 8);
 #define FC_LAUNCH(MODE_, HM_)                                                                              \
   {                                                                                                        \

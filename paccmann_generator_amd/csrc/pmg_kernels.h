@@ -95,6 +95,13 @@ struct FwdArgs {
   float* CX; unsigned* CXS;
   int cluster_gtab_lds;    // set by pmg_launch_fwdc: the token-table lines of a member's units fit its LDS
   int cluster_ng;          // set by pmg_launch_fwdc: row groups per cluster
+  int cluster_hist_t;      // set by pmg_launch_fwdc: stack / push / probability history per SEQUENCE (see LAYW)
+  // History layout word (training workspaces of cluster-capable shapes, else NULL): 0 = the stack (SB), push
+  // value (PV) and probability (PR) slabs interleave the 16 sequences of a row group innermost (what the
+  // batch-partitioned kernels read and write); nonzero = one contiguous run per sequence, written by the
+  // clustered forward when the clustered BPTT will read it.  Set by the forward launch (stream-ordered),
+  // checked by the BPTT kernels: the batch-partitioned one poisons its outputs when it finds nonzero.
+  unsigned* LAYW;
   const float* w_ctrl; const float* b_ctrl; const float* w_push; const float* b_push;
   const float* w_out; const float* b_out;
 };
@@ -139,6 +146,7 @@ struct BwdArgs {
   // clustered BPTT (pmg_bwdc.hip): exchange buffers, counters, caller's flags
   float* CX; unsigned* CXS; uint32_t flags;
   int cluster_ng;             // set by pmg_launch_bwdc: row groups per cluster
+  const unsigned* LAYW;       // history layout word (FwdArgs::LAYW)
 };
 
 hipError_t pmg_launch_bwd(const BwdArgs* a, hipStream_t st);
@@ -148,3 +156,5 @@ int pmg_bwd_chunk_buffers(const BwdArgs* a);
 bool pmg_bwdc_applicable(const BwdArgs* a);
 hipError_t pmg_launch_bwdc(const BwdArgs* a, hipStream_t st);
 size_t pmg_bwdc_cx_floats(const PmgDims& d);
+// would the clustered BPTT serve this shape (flags aside)?  The clustered forward asks before it picks the history layout.
+bool pmg_bwdc_shape_ok(int H, int L, int NX, int NXT, int V, int W, int D, int G);

@@ -26,3 +26,8 @@ with torch.no_grad():
 print('teacher:', flush=True)
 ops.teacher_forced_logprobs(w, padded, h0)
 torch.cuda.synchronize()
+print('bptt:', flush=True)
+rewards = torch.rand(B, device=dev)
+from paccmann_generator_amd import _ffi
+loss, logp = ops.reinforce_loss(w, padded, h0.requires_grad_(True), rewards, 1.0 / B)
+torch.cuda.synchronize()
