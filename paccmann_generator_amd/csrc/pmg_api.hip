@@ -30,7 +30,7 @@ static size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
 
 // shapes the clustered forward may serve (pmg_fwdc_applicable decides per call): room for its
 // exchange buffers is laid out only then
-static bool cluster_shape(const PmgDims& d) { return d.L == 1 && d.H <= 512 && pmg_cluster_ng(d.G, d.H) <= PMG_CLUSTER_NG_MAX; }
+static bool cluster_shape(const PmgDims& d) { return d.L == 1 && d.H <= 512 && pmg_cluster_ng(d.G, d.H) <= pmg_cluster_ng_limit(d.H); }
 
 static void make_layout(const PmgDims& d, int mode, PmgLayout* L) {
   memset(L, 0, sizeof(*L));

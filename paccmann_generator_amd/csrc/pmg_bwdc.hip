@@ -526,7 +526,7 @@ size_t pmg_bwdc_cx_floats(const PmgDims& d) {
 bool pmg_bwdc_shape_ok(int H, int L, int NX, int NXT, int V, int W, int D, int G) {
   if (L != 1 || H > 512 || NX > 256 || V > 264) return false;
   const int ng = pmg_cluster_ng(G, H);
-  if (ng > PMG_CLUSTER_NG_MAX) return false;
+  if (ng > pmg_cluster_ng_limit(H)) return false;
   if (BC_THREADS / W < 1) return false;
   BwdArgs t;
   t.H = H; t.NXT = NXT; t.D = D; t.W = W;

@@ -688,7 +688,7 @@ bool pmg_fwdc_applicable(const FwdArgs* a) {
   if (a->mode != PMG_FWD_DECODE && a->mode != PMG_FWD_TEACHER) return false;
   if (a->L != 1 || a->H > 512 || a->NX > 256 || a->CX == nullptr) return false;
   const int ng = pmg_cluster_ng(a->G, a->H);
-  if (ng > PMG_CLUSTER_NG_MAX) return false;
+  if (ng > pmg_cluster_ng_limit(a->H)) return false;
   return fwdc_lds_base_bytes(a, ng) <= (size_t)160 * 1024;
 }
 

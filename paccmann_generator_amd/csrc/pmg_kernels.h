@@ -114,6 +114,10 @@ static inline int pmg_cluster_ng(int G, int H) {
   const int ncl = 8 * (32 / (H / 16));
   return (G + ncl - 1) / ncl;
 }
+// Row groups per cluster up to which the clustered kernels beat the batch-partitioned ones (measured,
+// profiles/r03_cluster_groups.md): the smaller the hidden size, the cheaper a batch-partitioned step and the
+// larger the share of the per-sequence owner work.
+static inline int pmg_cluster_ng_limit(int H) { return H >= 384 ? PMG_CLUSTER_NG_MAX : H >= 256 ? 4 : 1; }
 // clustered forward for small batches (pmg_fwdc.hip); pmg_launch_fwd picks it by shape
 bool pmg_fwdc_applicable(const FwdArgs* a);
 hipError_t pmg_launch_fwdc(const FwdArgs* a, hipStream_t st);

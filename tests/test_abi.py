@@ -126,13 +126,20 @@ def test_cluster_path_selection_by_shape():
     def uses(B, H, L=1, V=60, flags=0, mode=_ffi.PMG_MODE_DECODE, T=100):
         s = _ffi.make_shape(B, T, H, 128, 50, 50, V, L, 256, 0)
         return _ffi.lib.pmg_uses_cluster(C.byref(s), mode, flags)
-    assert uses(64, 256) == 1 and uses(64, 256, mode=_ffi.PMG_MODE_TRAIN, T=102) == 3      # BASELINE configs[0]: forward and BPTT
-    assert uses(256, 256) == 1 and uses(257, 256) == 0          # 16 clusters of 16 CUs fill the chip
-    assert uses(128, 512) == 1 and uses(129, 512) == 0          # conditional_generator.json:12 at hidden 512
-    assert uses(512, 128) == 1 and uses(96, 384) == 1 and uses(144, 384) == 0
-    assert uses(4096, 512) == 0                                  # configs[1]: batch-partitioned
+    TR = _ffi.PMG_MODE_TRAIN
+    assert uses(64, 256) == 1 and uses(64, 256, mode=TR, T=102) == 3      # BASELINE configs[0]: forward and BPTT
+    # 16 clusters of 16 CUs fill the chip at hidden 256; above that a cluster serves several row groups, up to
+    # four (beyond, the batch-partitioned kernels are as fast); the BPTT's owned sequences fit the LDS up to three
+    assert uses(256, 256) == 1 and uses(257, 256) == 1 and uses(1024, 256) == 1 and uses(1025, 256) == 0
+    assert uses(768, 256, mode=TR) == 3 and uses(769, 256, mode=TR) == 1 and uses(1025, 256, mode=TR) == 0
+    # conditional_generator.json:12 at hidden 512: 8 clusters of 32 CUs, up to six row groups each (LDS)
+    assert uses(128, 512) == 1 and uses(768, 512) == 1 and uses(769, 512) == 0
+    assert uses(128, 512, mode=TR) == 3 and uses(768, 512, mode=TR) == 3 and uses(769, 512, mode=TR) == 0
+    assert uses(512, 128) == 1 and uses(513, 128) == 0          # hidden 128: one row group per cluster only
+    assert uses(96, 384) == 1 and uses(896, 384) == 1 and uses(897, 384) == 0
+    assert uses(512, 384, mode=TR) == 3 and uses(513, 384, mode=TR) == 1
+    assert uses(4096, 512) == 0 and uses(4096, 512, mode=TR) == 0          # configs[1]: batch-partitioned
     assert uses(64, 256, L=2) == 0 and uses(64, 640) == 0 and uses(64, 256, V=300) == 0
     assert uses(64, 256, flags=_ffi.PMG_FLAG_NO_CLUSTER) == 0
-    assert uses(128, 512, mode=_ffi.PMG_MODE_TRAIN) == 3 and uses(4096, 512, mode=_ffi.PMG_MODE_TRAIN) == 0
-    assert uses(64, 256, mode=_ffi.PMG_MODE_TRAIN, flags=_ffi.PMG_FLAG_NO_CLUSTER) == 0
+    assert uses(64, 256, mode=TR, flags=_ffi.PMG_FLAG_NO_CLUSTER) == 0
     assert uses(64, 100) < 0

@@ -52,6 +52,70 @@ def test_small_batch_cluster_edges(gpu, H, V, W, D, B, T):
     assert P.check_greedy(cfg, B, T)['mismatched_rows'] == 0
 
 
+@pytest.mark.parametrize('H,B', [(256, 300), (256, 1000), (512, 200), (512, 700), (384, 250), (384, 890)])
+def test_several_row_groups_per_cluster(gpu, H, B):
+    """More row groups than resident clusters: a cluster serves several (pmg_fwdc.hip / pmg_bwdc.hip), a member
+    owns several sequences; where the BPTT's owned sequences no longer fit the LDS (B=1000 at hidden 256, 890 at
+    384) the clustered forward is paired with the batch-partitioned BPTT."""
+    cfg = dict(MID, rnn_cell_size=H)
+    P.check_train(cfg, B=B, T=14, tol=TOL)
+    assert P.check_greedy(cfg, B, 16)['mismatched_rows'] == 0
+    r = P.check_sampling(cfg, B, 12, temperature=1.1)
+    assert r['exact'] + r['boundary'] == B * 12 and r['boundary'] <= 2
+
+
+def test_reference_stack_hidden_512_three_owned_sequences(gpu):
+    cfg = dict(P.CFG1, rnn_cell_size=512)       # stack 50x50: six row groups per cluster is what the LDS holds
+    P.check_train(cfg, B=760, T=60, tol=TOL)
+
+
+def test_history_layout_follows_the_forward(gpu, forward_path):
+    """The clustered forward leaves stack / push / probability history per sequence when the clustered BPTT
+    will read it (FwdArgs::LAYW).  A BPTT told PMG_FLAG_NO_CLUSTER on such a workspace must not return
+    plausible numbers; a clustered BPTT after a batch-partitioned forward reads the interleaved layout."""
+    import ctypes as C
+    from paccmann_generator_amd import _ffi, ops
+    if forward_path != 'clustered':
+        pytest.skip('one pass is enough')
+    cfg = dict(MID, rnn_cell_size=256)
+    _, pdec = P.make_pair(cfg, seed=2)
+    w = pdec.weights()
+    B, T = 40, 12
+    tokens = P.synthetic_tokens(T, B, cfg['vocab_size'], seed=3).cuda()
+    torch.manual_seed(4)
+    h0 = torch.tanh(torch.randn(1, B, 256)).cuda()
+    reward = torch.rand(B).cuda()
+    params = [p.detach() for p in w.flat()]
+    d = ops._dims_of(params, w.dims['D'], w.pad_idx)
+    shape = ops._shape(d, B, T)
+    wstruct, keep = ops._wstruct(params, 1)
+
+    def run(fwd_flags, bwd_flags):
+        ws = ops._alloc_ws(shape, _ffi.PMG_MODE_TRAIN, h0.device)
+        logp = torch.empty(T - 1, B, device='cuda')
+        _ffi.check(_ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(tokens), _ffi._ptr(h0),
+                                            _ffi._ptr(logp), None, fwd_flags, _ffi._ptr(ws), _ffi.current_stream()), 'fwd')
+        grads = [torch.empty_like(p) for p in params]
+        gstruct, keep2 = ops._grad_struct(grads, 1)
+        gh0 = torch.empty_like(h0)
+        loss = torch.empty(1, device='cuda')
+        _ffi.check(_ffi.lib.pmg_reinforce_bwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(tokens), _ffi._ptr(reward),
+                                              1.0 / B, bwd_flags, C.byref(gstruct), _ffi._ptr(gh0), _ffi._ptr(loss),
+                                              _ffi._ptr(ws), _ffi.current_stream()), 'bwd')
+        torch.cuda.synchronize()
+        return loss.item(), gh0, grads
+
+    NC = _ffi.PMG_FLAG_NO_CLUSTER
+    ref = run(NC, NC)
+    for ff, bf in ((0, 0), (NC, 0)):
+        l, g, gs = run(ff, bf)
+        assert abs(l - ref[0]) <= 1e-5 * abs(ref[0])
+        assert torch.allclose(g, ref[1], rtol=1e-4, atol=1e-7)
+        assert all(torch.allclose(x, y, rtol=2e-4, atol=1e-6) for x, y in zip(gs, ref[2]))
+    l, g, _ = run(0, NC)
+    assert l != l and bool(torch.isnan(g).all())
+
+
 def test_wide_vocabulary_with_the_reference_stack_and_hidden_768(gpu):
     cfg = dict(P.CFG1, rnn_cell_size=768, vocab_size=575)
     P.check_train(cfg, B=17, T=20, tol=TOL)
