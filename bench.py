@@ -239,6 +239,13 @@ def _uses_cluster(learner, B, T):
     return _ffi.lib.pmg_uses_cluster(C.byref(shape), _ffi.PMG_MODE_DECODE, ops._cluster_flag()) == 1
 
 
+def _bptt_uses_cluster(learner, B, T):
+    import ctypes as C
+    from paccmann_generator_amd import _ffi, ops
+    shape = learner.generator.decoder.weights().shape(B, T + 2)
+    return (_ffi.lib.pmg_uses_cluster(C.byref(shape), _ffi.PMG_MODE_TRAIN, ops._cluster_flag()) & 2) != 0
+
+
 def rank_command(n_gpus: int, argv, port: int):
     """Command line that starts the N ranks of `bench.py --gpus N` (one process per GPU on one node)."""
     return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_gpus}',
@@ -397,6 +404,7 @@ def main():
         'replicas_identical': replicas_identical,     # N>1: checked over all ranks after the timed steps
         'dist_backend': (dist.get_backend(pg) if pg is not None else None),
         'forward_kernels': 'clustered' if _uses_cluster(learner, B, T) else 'batch-partitioned',
+        'bptt_kernels': 'clustered' if _bptt_uses_cluster(learner, B, T) else 'batch-partitioned',
     }
     if rank == 0:
         if not args.no_phases:

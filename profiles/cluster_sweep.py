@@ -17,7 +17,7 @@ def timed(f, n=3):
     return (time.perf_counter() - t) / n * 1e3
 
 T = 100
-for H, Bs in [(128, [256, 512, 1024, 2048]), (384, [128, 256, 384, 512]), (256, [256, 512, 768, 1024, 1280]), (512, [128, 256, 512, 768])]:
+for H, Bs in [(128, [256, 512]), (256, [64, 256, 512, 768, 1024]), (384, [128, 256, 512, 896]), (512, [128, 256, 512, 768])]:
     cfg = dict(P.CFG1, rnn_cell_size=H)
     _, pdec = P.make_pair(cfg, seed=0)
     w = pdec.weights()
