@@ -40,8 +40,12 @@ extern "C" {
                                      may differ): skip the packing kernels.  For batches run in chunks. */
 
 #define PMG_FLAG_NO_CLUSTER 32u   /* decode / logprob_fwd / reinforce_bwd / reinforce_bptt: never take the clustered small-batch kernels (see below).
-                                     Pass it on launches that may run CONCURRENTLY with another pmg_decode /
-                                     pmg_logprob_fwd on the same GPU (other streams or processes). */
+                                     Pass it on launches that may run CONCURRENTLY with another pmg launch on the
+                                     same GPU (other streams or processes), and pass it to pmg_reinforce_bwd /
+                                     pmg_reinforce_bptt whenever the pmg_logprob_fwd that filled the workspace had
+                                     it and vice versa: a backward with the flag on a workspace whose forward ran
+                                     without it returns NaN (the clustered forward keeps part of the history in a
+                                     layout only the clustered backward reads). */
 
 typedef void* pmg_stream; /* hipStream_t */
 
@@ -102,10 +106,12 @@ int pmg_check_shape(const pmg_shape* s, int mode);
 /* Which launches would take the clustered small-batch kernels for shape `s` with these flags:
  * PMG_MODE_DECODE: 1 if pmg_decode does; PMG_MODE_TRAIN: bit 0 for pmg_logprob_fwd, bit 1 for
  * pmg_reinforce_bptt (the recurrent half of pmg_reinforce_bwd); 0 = the batch-partitioned kernels,
- * negative for an unsupported shape.  Clustered: one layer, H <= 512, B <= 16 * 8 * floor(512 / H)
- * sequences, 3+W+V <= 256; a cluster of H/16 workgroups (one per CU) serves 16 sequences and
- * synchronises through device memory twice per time step, so every cluster member must be resident
- * at once: see PMG_FLAG_NO_CLUSTER.  Same results either way (to the tolerances of the parity
+ * negative for an unsupported shape.  Clustered: one layer, H <= 512, 3+W+V <= 256, and at most NG row
+ * groups of 16 sequences per cluster where there are 8 * floor(512 / H) clusters: NG = 1 at H = 128,
+ * up to 4 at H = 256 (B <= 1024), above that as many as the owned sequences' stacks fit the CU's LDS
+ * (6 at H = 512 with a 50 x 50 stack: B <= 768; the BPTT stops a little earlier).  A cluster of H/16
+ * workgroups (one per CU) synchronises through device memory twice per time step, so every cluster
+ * member must be resident at once: see PMG_FLAG_NO_CLUSTER.  Same results either way (to the tolerances of the parity
  * tests; greedy tokens exact). */
 int pmg_uses_cluster(const pmg_shape* s, int mode, uint32_t flags);
 
