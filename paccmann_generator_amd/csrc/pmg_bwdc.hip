@@ -53,6 +53,9 @@ __device__ __forceinline__ void cluster_arrive(unsigned* ctr) {
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// RAW: the closing workgroup barrier without the fence of __syncthreads(), which drains the vector-memory counter:
+// loads requested on purpose in front of the wait (next step's gates and history) stay in flight across it.
+template <bool RAW = false>
 __device__ __forceinline__ bool cluster_wait(unsigned* ctr, const unsigned target, unsigned* status, int* okw) {
   if (threadIdx.x == 0) {
     int ok = 1;
@@ -67,7 +70,8 @@ __device__ __forceinline__ bool cluster_wait(unsigned* ctr, const unsigned targe
     }
     *okw = ok;
   }
-  __syncthreads();
+  if (RAW) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else __syncthreads();
   return *okw != 0;
 }
 
@@ -91,7 +95,7 @@ __host__ __device__ inline BcLds bc_lds(const int NXT, const int NOWN, const int
   o.dtls = p; p += (unsigned)NOWN * 64;     // [NOWN][64] dtop
   o.r3s = p; p += (unsigned)NOWN * 32;      // [NOWN][8][4] control-gradient partials per wave
   o.dxls = p; p += (unsigned)NOWN * 256;    // [NOWN][256] dx
-  o.hist = p; p += (unsigned)NOWN * BC_HIST;   // forward history of the step, fetched under barrier A
+  o.hist = p; p += (unsigned)NOWN * BC_HIST;   // [NOWN][..] forward history of the step, fetched under barrier A
   o.sprevs = p; p += (unsigned)NOWN * DW;   // [NOWN][D*W] S_{p-1}, fetched under barrier A
   o.dsb = p; p += (unsigned)NOWN * 2 * DW;  // [NOWN][2][D*W] stack gradient ping-pong
   o.misc = p; p += 64;
@@ -161,6 +165,7 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
   unsigned bars = 0;
 #define BC_ARRIVE() (++bars, cluster_arrive(ctr))
 #define BC_WAIT() cluster_wait(ctr, (unsigned)C * bars, status, misc)
+#define BC_WAIT_RAW() cluster_wait<true>(ctr, (unsigned)C * bars, status, misc)
 #ifdef PMG_PROFILE
   // -DPMG_PROFILE build + PMG_DEBUG bit 0x8000: per-phase cycle counters of member 0 of cluster 0
   const bool prof = (a.dbg & 0x8000) != 0 && cl == 0 && cu == 0;
@@ -208,67 +213,84 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
   bool ok = true;
   // Forward history of step p for every owned sequence -> LDS: S_{p-1}, push values, controls, log-prob, target
   // token, probabilities.  Plain loads of what the forward wrote long ago; issued under the wait of barrier A.
-  auto fetch_history = [&](const int p) {
+  // fetch in two halves: fetch_issue requests round m0 of a step's history into registers (8 stack elements per thread
+  // ACROSS the owned sequences, and for two sequences the small items), fetch_commit puts them into LDS.
+  float fv[8], f1[2], f2[2];
+  const int rpt = (D + SDS - 1) / SDS, MF = nown * rpt;      // stack elements per thread and step
+  auto fetch_issue = [&](const int p, const int m0, const int k0) __attribute__((always_inline)) {
     const bool virt = (p == N);
-    if (!virt) {
-      // S_{p-1} of every owned sequence: rows <= min(p-1, N-p, D-1) hold data (pmg_fwd.hip "live rows"), the rest
-      // is zero.  Eight loads in flight per thread ACROSS the owned sequences: one memory latency, not one per sequence.
-      const int s_hi = (p == 0) ? -1 : min(min(p - 1, N - p), D - 1);
-      const int rpt = (D + SDS - 1) / SDS, M = nown * rpt;
-      for (int m0 = 0; m0 < M; m0 += 8) {
-        float v[8];
+    // S_{p-1}: rows <= min(p-1, N-p, D-1) hold data (pmg_fwd.hip "live rows"), the rest is zero
+    const int s_hi = (virt || p == 0) ? -1 : min(min(p - 1, N - p), D - 1);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int m = m0 + u, k = m / rpt, d = sd0 + (m - k * rpt) * SDS;
-          const int sg = cu + k * C, s = sg & 15, g = g0 + (sg >> 4);
-          v[u] = 0.0f;
-          if (m < M && sw < W && d <= s_hi) {
-            const float* Sp = a.SB + ((size_t)p * G + g) * a.SW;
-            v[u] = Sp[ht ? (size_t)s * DW + d * W + sw : (size_t)(d * W + sw) * 16 + s];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int m = m0 + u, k = m / rpt, d = sd0 + (m - k * rpt) * SDS;
-          if (m < M && sw < W && d < D) sprevs[(size_t)k * DW + d * W + sw] = v[u];
-        }
+    for (int u = 0; u < 8; ++u) {
+      const int m = m0 + u, k = m / rpt, d = sd0 + (m - k * rpt) * SDS;
+      const int sg = cu + k * C, s = sg & 15, g = g0 + (sg >> 4);
+      fv[u] = 0.0f;
+      if (m < MF && sw < W && d <= s_hi) {
+        const float* Sp = a.SB + ((size_t)p * G + g) * a.SW;
+        fv[u] = Sp[ht ? (size_t)s * DW + d * W + sw : (size_t)(d * W + sw) * 16 + s];
       }
     }
-    // push values, controls, log-prob, target token (one thread each) and probabilities: four sequences per round
-    for (int k0 = 0; k0 < nown; k0 += 4) {
-      float v1[4], v2[4];
+    // push values, controls, log-prob, target token (one thread each) and probabilities
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = k0 + u;
-        const int sg = cu + k * C, s = sg & 15, g = g0 + (sg >> 4), row = row00 + sg;
-        v1[u] = 0.0f; v2[u] = 0.0f;
-        if (k < nown) {
-          if (!virt) {
-            if (tid < W) v1[u] = a.PV[((size_t)p * G + g) * 1024 + (ht ? s * 64 + tid : tid * 16 + s)];
-            else if (tid >= 64 && tid < 67) v1[u] = a.CT[((size_t)p * G + g) * 64 + (tid - 64) * 16 + s];
-          }
-          if (p >= 1) {
-            if (tid == 67) v1[u] = a.LP[((size_t)(p - 1) * G + g) * 16 + s];
-            if (tid == 68) v1[u] = __int_as_float((row < B) ? min(max((int)a.tokens[(size_t)p * B + row], 0), V - 1) : 0);
-            if (tid >= 128 && tid < 128 + V)
-              v2[u] = a.PR[((size_t)(p - 1) * G + g) * a.VP * 16 + (ht ? s * a.VP + tid - 128 : (tid - 128) * 16 + s)];
-          }
+    for (int u = 0; u < 2; ++u) {
+      const int k = k0 + u;
+      const int sg = cu + k * C, s = sg & 15, g = g0 + (sg >> 4), row = row00 + sg;
+      f1[u] = 0.0f; f2[u] = 0.0f;
+      if (k < nown) {
+        if (!virt) {
+          if (tid < W) f1[u] = a.PV[((size_t)p * G + g) * 1024 + (ht ? s * 64 + tid : tid * 16 + s)];
+          else if (tid >= 64 && tid < 67) f1[u] = a.CT[((size_t)p * G + g) * 64 + (tid - 64) * 16 + s];
         }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = k0 + u;
-        if (k < nown) {
-          float* hk = hist + k * BC_HIST;
-          if (!virt && (tid < W || (tid >= 64 && tid < 67))) hk[tid] = v1[u];
-          if (p >= 1) {
-            if (tid == 67 || tid == 68) hk[tid] = v1[u];
-            if (tid >= 128 && tid < 128 + V) hk[72 + tid - 128] = v2[u];
-          }
+        if (p >= 1) {
+          if (tid == 67) f1[u] = a.LP[((size_t)(p - 1) * G + g) * 16 + s];
+          if (tid == 68) f1[u] = __int_as_float((row < B) ? min(max((int)a.tokens[(size_t)p * B + row], 0), V - 1) : 0);
+          if (tid >= 128 && tid < 128 + V)
+            f2[u] = a.PR[((size_t)(p - 1) * G + g) * a.VP * 16 + (ht ? s * a.VP + tid - 128 : (tid - 128) * 16 + s)];
         }
       }
     }
   };
+  auto fetch_commit = [&](const int p, const int m0, const int k0) __attribute__((always_inline)) {
+    const bool virt = (p == N);
+    if (!virt) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int m = m0 + u, k = m / rpt, d = sd0 + (m - k * rpt) * SDS;
+        if (m < MF && sw < W && d < D) sprevs[(size_t)k * DW + d * W + sw] = fv[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = k0 + u;
+      if (k < nown) {
+        float* hk = hist + k * BC_HIST;
+        if (!virt && (tid < W || (tid >= 64 && tid < 67))) hk[tid] = f1[u];
+        if (p >= 1) {
+          if (tid == 67 || tid == 68) hk[tid] = f1[u];
+          if (tid >= 128 && tid < 128 + V) hk[72 + tid - 128] = f2[u];
+        }
+      }
+    }
+  };
+  // the whole history of a step, round by round (one memory latency per round)
+  auto fetch_history = [&](const int p) __attribute__((always_inline)) {
+    for (int m0 = 0, k0 = 0; m0 < MF || k0 < nown; m0 += 8, k0 += 2) {
+      fetch_issue(p, m0, k0);
+      fetch_commit(p, m0, k0);
+    }
+  };
+  // saved gates and previous hidden state of the NEXT step's cell backward (wave r, own units of group r): requested
+  // under barrier A next to the history fetch, a whole step before they are used
+  f32x4 pg0 = z4, pg1 = z4, pg2 = z4, pg3 = z4, pg4 = z4;
+  auto load_gates = [&](const int pp) __attribute__((always_inline)) {
+    const float* gp = a.GT[0] + (((size_t)pp * G + gw) * KG + cu) * 1024 + lane * 4;
+    pg0 = ld4(gp); pg1 = ld4(gp + 256); pg2 = ld4(gp + 512); pg3 = ld4(gp + 768);
+    const float* hh = a.HH[0] + (((size_t)pp * G + gw) * H + 16 * cu + 4 * q) * 16 + b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pg4[j] = hh[j * 16];
+  };
+  if (mygrp && N >= 1) load_gates(N - 1);
 
   for (int p = N; p >= 0 && ok; --p) {
     const bool virt = (p == N);
@@ -277,12 +299,7 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
     if (!virt) {
       f32x4 gr = z4, gz = z4, gn = z4, gg = z4;    // dr_pre, dz_pre, dn_pre, dghn
       if (mygrp) {
-        const float* gp = a.GT[0] + (((size_t)p * G + gw) * KG + cu) * 1024 + lane * 4;
-        const f32x4 r = ld4(gp), z = ld4(gp + 256), n = ld4(gp + 512), ghn = ld4(gp + 768);
-        const float* hh = a.HH[0] + (((size_t)p * G + gw) * H + 16 * cu + 4 * q) * 16 + b;
-        f32x4 hp;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) hp[j] = hh[j * 16];
+        const f32x4 r = pg0, z = pg1, n = pg2, ghn = pg3, hp = pg4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float d = car[j];
@@ -328,7 +345,8 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
         }
       }
       fetch_history(p);
-      if (!(ok = BC_WAIT())) break;              // A: every member's dgate blocks and dtop partials visible
+      if (mygrp && p >= 1) load_gates(p - 1);
+      if (!(ok = BC_WAIT_RAW())) break;          // A: every member's dgate blocks and dtop partials visible
       BC_TICK(1)
     }
 
@@ -339,12 +357,17 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
       for (int k = wave; k < nown; k += 8) {
         const int sg = cu + k * C, r = sg >> 4, s = sg & 15;
         const int tt = lane >> 4, kq = (lane >> 2) & 3, j = lane & 3;
-        float v[C];
-#pragma unroll
-        for (int cm = 0; cm < C; ++cm) v[cm] = xld1(ptb, (unsigned)((((r * C + cm) * 4 + tt) * 256 + (s + 16 * kq) * 4 + j)) * 4u);
+        constexpr int CH = C < 16 ? C : 16;        // partials requested per round
         float acc = 0.0f;
 #pragma unroll
-        for (int cm = 0; cm < C; ++cm) acc += v[cm];
+        for (int c0 = 0; c0 < C; c0 += CH) {
+          float v[CH];
+#pragma unroll
+          for (int cm = 0; cm < CH; ++cm)
+            v[cm] = (c0 + cm < C) ? xld1(ptb, (unsigned)((((r * C + c0 + cm) * 4 + tt) * 256 + (s + 16 * kq) * 4 + j)) * 4u) : 0.0f;
+#pragma unroll
+          for (int cm = 0; cm < CH; ++cm) acc += v[cm];
+        }
         dtls[k * 64 + lane] = acc;
       }
     __syncthreads();
@@ -464,18 +487,24 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
     // ================================================================ members: the new carry of the own units, one wave per group
     if (mygrp) {
       f32x4 acc0 = virt ? z4 : dhz + hhs, acc1 = z4;
-      for (int kg = 0; kg < NXT; kg += 2) {
-        const f32x4 x0 = xld4(dxb, (unsigned)((wave * 16 + b) * 256 + 16 * kg + 4 * q) * 4u);
-        const f32x4 w0 = ld4(wt_x + (size_t)kg * 256 + lane * 4);
-        f32x4 x1 = z4, w1 = z4;
-        if (kg + 1 < NXT) {
-          x1 = xld4(dxb, (unsigned)((wave * 16 + b) * 256 + 16 * (kg + 1) + 4 * q) * 4u);
-          w1 = ld4(wt_x + (size_t)(kg + 1) * 256 + lane * 4);
-        }
+      // every dx block of a round is requested before the first product: one L2 round trip per eight reduction groups
+      for (int kg0 = 0; kg0 < NXT; kg0 += 8) {
+        f32x4 xr[8];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[c], x0[c], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[c], x1[c], acc1, 0, 0, 0);
+        for (int u = 0; u < 8; ++u)
+          xr[u] = (kg0 + u < NXT) ? xld4(dxb, (unsigned)((wave * 16 + b) * 256 + 16 * (kg0 + u) + 4 * q) * 4u) : z4;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (kg0 + u < NXT) {
+            const f32x4 wv = ld4(wt_x + (size_t)(kg0 + u) * 256 + lane * 4);
+            if (u & 1) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c], xr[u][c], acc1, 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c], xr[u][c], acc0, 0, 0, 0);
+            }
+          }
         }
       }
       car = acc0 + acc1;
