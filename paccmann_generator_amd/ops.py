@@ -422,6 +422,8 @@ def _reinforce_setup(ctx, inputs, output):
     tokens, h0, reward, scale, params, stack_depth, pad_idx, chunk, with_grads = inputs
     _, _, grad_h0, grads = output
     ctx.with_grads = bool(with_grads)
+    # logp, grad_h0 and grads are results, not differentiable outputs: no zero tensors for their missing gradients
+    ctx.set_materialize_grads(False)
     ctx.n_params = len(params)
     ctx.h0_dtype = h0.dtype
     ctx.save_for_backward(grad_h0, *grads)
@@ -432,6 +434,8 @@ def _reinforce_backward(ctx, g_loss, g_logp, g_gh0, g_grads):
     gradient of the scalar loss.  logp, grad_h0 and grads are results, not differentiable outputs."""
     if not ctx.with_grads:
         raise RuntimeError('pmg::reinforce_loss was called with with_grads=False: no gradient was formed')
+    if g_loss is None:
+        return (None,) * 9
     grad_h0, *grads = ctx.saved_tensors
     gl = g_loss.to(torch.float32)
     scaled = list(torch._foreach_mul(grads, gl)) if grads else []      # one multi-tensor launch, not 4L+7
