@@ -89,6 +89,10 @@ class _CroppedRows:
     def __init__(self, tokens_cpu: torch.Tensor, lens_cpu: torch.Tensor):
         self.tokens = tokens_cpu
         self.lens = lens_cpu
+        if lens_cpu.numel() and int(lens_cpu.min()) < 0:
+            from . import _ffi
+            raise _ffi.PmgError('pmg_decode gave up on a cluster barrier (lengths poisoned with -1): another kernel '
+                                'held the CUs; pass PMG_FLAG_NO_CLUSTER on launches that overlap (include/pmg.h)')
 
     def __iter__(self):
         for row, n in zip(self.tokens, self.lens.tolist()):

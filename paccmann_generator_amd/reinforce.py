@@ -24,7 +24,7 @@ from typing import Callable, Optional
 import numpy as np
 import torch
 
-from . import dp, ops
+from . import _ffi, dp, ops
 from .decoder import SamplingSearch
 
 
@@ -292,7 +292,7 @@ class Reinforce(object):
             rewards = self.get_reward(valid_smiles, target)
             padded_nums, trusted = self._padded_valid(valid_nums, valid_idx, t_max)
         r, loss = self.learn(latent_z, padded_nums, valid_idx, rewards, self._lrps(), trusted_tokens=trusted)
-        return r, float(loss)
+        return r, _loss_value(loss)
 
     # ------------------------------------------------------------------ pipelined step
     def _policy_gradient_pipelined(self, latent_z, target):
@@ -386,14 +386,14 @@ class Reinforce(object):
             r, loss, _ = dp.data_parallel_step(dec_params, enc_params, self.optimizer, lambda: run(1.0), n_valid,
                                                lambda: float(sum(float(x.sum(dtype=np.float64)) for x in rewards_all)),
                                                self.grad_clipping, group=self.process_group)
-            return r, float(loss)
+            return r, _loss_value(loss)
         self.optimizer.zero_grad()
         loss = run(1.0 / n_valid)
         r = torch.mean(torch.from_numpy(np.concatenate(rewards_all)).float())
         if self.grad_clipping is not None:
             torch.nn.utils.clip_grad_norm_(dec_params + enc_params, self.grad_clipping)
         self.optimizer.step()
-        return r, float(loss)
+        return r, _loss_value(loss)
 
     @staticmethod
     def _local_t_max(valid_nums, valid_idx) -> int:
@@ -612,7 +612,11 @@ class StopRows:
 
     def _rows(self):
         if self._host is None:
-            self._host = (self.tokens.cpu(), self.lens.cpu().tolist(), torch.tensor(2 * [self.stop_index]))
+            lens = self.lens.cpu().tolist()
+            if lens and min(lens) < 0:
+                raise _ffi.PmgError('pmg_decode gave up on a cluster barrier (lengths poisoned with -1): another kernel '
+                                    'held the CUs; pass PMG_FLAG_NO_CLUSTER on launches that overlap (include/pmg.h)')
+            self._host = (self.tokens.cpu(), lens, torch.tensor(2 * [self.stop_index]))
         return self._host
 
     def __len__(self):
@@ -627,6 +631,18 @@ class StopRows:
 
     def __iter__(self):
         return (self[i] for i in range(len(self.index)))
+
+
+def _loss_value(loss) -> float:
+    """The step's loss on the host.  NaN is reported loudly: a clustered launch that gave up on a barrier poisons
+    its outputs with NaN (include/pmg.h, PMG_FLAG_NO_CLUSTER) and the update that followed is not to be trusted;
+    a policy that diverged by itself deserves the same message."""
+    v = float(loss)
+    if v != v:
+        raise _ffi.PmgError('pmg: the REINFORCE loss is NaN -- a clustered launch gave up on a cluster barrier '
+                            '(another kernel held the CUs: see PMG_FLAG_NO_CLUSTER in include/pmg.h) or the '
+                            'policy diverged; the parameters were updated with it')
+    return v
 
 
 def pad_rows_on_device(tokens: torch.Tensor, lens: torch.Tensor, stop_index: int, t_max: Optional[int] = None):

@@ -114,3 +114,24 @@ def test_stop_rows_is_the_lazy_twin_of_the_reference_row_list():
     assert [r.tolist() for r in rows[1:3]] == [ref[1].tolist(), ref[2].tolist()]
     padded = torch.nn.utils.rnn.pad_sequence(list(sub))          # reinforce_omics.py:304 accepts it
     assert padded.shape == (7, 3) and padded[:, 0].tolist() == ref[1].tolist() + [0, 0]
+
+
+def test_poisoned_outputs_of_a_clustered_launch_are_reported():
+    """A clustered launch that gives up on a barrier poisons its outputs (include/pmg.h): lengths of -1 after
+    pmg_decode, NaN loss after the training pair.  The host mirror turns both into PmgError instead of
+    cropping with negative lengths or logging NaN."""
+    import pytest
+    import torch
+    from paccmann_generator_amd import _ffi
+    from paccmann_generator_amd.decoder import _CroppedRows
+    from paccmann_generator_amd.reinforce import StopRows, _loss_value
+    tokens = torch.tensor([[5, 6, 3, 3], [7, 3, 3, 3]])
+    rows = StopRows(tokens, torch.tensor([2, -1], dtype=torch.int32), 3)
+    with pytest.raises(_ffi.PmgError, match='cluster barrier'):
+        rows[0]
+    with pytest.raises(_ffi.PmgError, match='cluster barrier'):
+        _CroppedRows(tokens, torch.tensor([-1, -1], dtype=torch.int32))
+    assert len(list(_CroppedRows(tokens, torch.tensor([2, 1], dtype=torch.int32)))) == 2
+    assert _loss_value(torch.tensor(0.25)) == 0.25
+    with pytest.raises(_ffi.PmgError, match='NaN'):
+        _loss_value(torch.tensor(float('nan')))
