@@ -637,7 +637,7 @@ def _loss_value(loss) -> float:
     """The step's loss on the host.  NaN is reported loudly: a clustered launch that gave up on a barrier poisons
     its outputs with NaN (include/pmg.h, PMG_FLAG_NO_CLUSTER) and the update that followed is not to be trusted;
     a policy that diverged by itself deserves the same message."""
-    v = float(loss)
+    v = float(loss.detach()) if isinstance(loss, torch.Tensor) else float(loss)
     if v != v:
         raise _ffi.PmgError('pmg: the REINFORCE loss is NaN -- a clustered launch gave up on a cluster barrier '
                             '(another kernel held the CUs: see PMG_FLAG_NO_CLUSTER in include/pmg.h) or the '
