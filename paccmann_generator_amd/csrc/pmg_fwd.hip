@@ -35,14 +35,18 @@ __device__ __forceinline__ f32x4 bl4(__amdgpu_buffer_rsrc_t r, unsigned voff, un
   f32x4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; return o;
 }
 // history stores of the teacher-forced pass (gates, hidden): written once, read once by the backward
-// much later; PMG_FWD_AUX_HIST = cache-policy bits of those stores (2 = nt).  Tuning knob.
+// much later; PMG_FWD_AUX_HIST = cache-policy bits of those stores (2 = nt).  Tuning knob for the shapes whose
+// packed weights fit the 4 MB L2s comfortably (measured neutral at cfg2); at hidden 1024 / two layers (40 MB of
+// packed weights living in the Infinity Cache) the streams go non-temporal: teacher-forced pass 161 -> 150 ms at
+// cfg4's shape on one box, the weights are no longer evicted by the history (profiles/r03_cfg4_nt.md).
 #ifndef PMG_FWD_AUX_HIST
 #define PMG_FWD_AUX_HIST 0
 #endif
+template <int AUX>
 __device__ __forceinline__ void bs4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const f32x4 v) {
   pmg_u32x4 u;
   u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
-  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, PMG_FWD_AUX_HIST);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, AUX);
 }
 // stack slab streams: cache-policy bits of the buffer instruction (bit 1 = nt) as a tuning knob
 #ifndef PMG_STACK_AUX_LD
@@ -61,8 +65,9 @@ __device__ __forceinline__ void bs4s(__amdgpu_buffer_rsrc_t r, unsigned voff, co
   u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
   __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, 0, PMG_STACK_AUX_ST);
 }
+template <int AUX>
 __device__ __forceinline__ void bs1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, PMG_FWD_AUX_HIST);
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, AUX);
 }
 
 // acc{r,z,t}[u0..u0+TPP) += W[tiles 3*u0 ..] * X   over KG groups of 16 columns.
@@ -389,6 +394,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
 template <int WV, int UPW, int TPP, int MODE, bool MULTI>
 __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs a) {
   constexpr int NTHR = WV * 64;
+  constexpr int HAUX = (MULTI || WV * UPW * 16 >= 1024) ? (PMG_FWD_AUX_HIST | 2) : PMG_FWD_AUX_HIST;   // history stores
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int H = a.H, HP = a.HP, XP = a.XP, W = a.W, D = a.D, V = a.V, L = a.L, B = a.B, G = a.G, N = a.N;
   const int KGH = a.KGH, UT = H / 16;
@@ -828,9 +834,10 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
         st4(hp_ptr, hn);
         if (keep) {
           const unsigned gs = (unsigned)ug * 4096u;
-          bs4(gth0, voff, gs, r); bs4(gth0, voff, gs + 1024u, z); bs4(gth0, voff, gs + 2048u, n); bs4(gth0, voff, gs + 3072u, vh);
+          bs4<HAUX>(gth0, voff, gs, r); bs4<HAUX>(gth0, voff, gs + 1024u, z); bs4<HAUX>(gth0, voff, gs + 2048u, n);
+          bs4<HAUX>(gth0, voff, gs + 3072u, vh);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) bs1(hhh0, vrow, (unsigned)((16 * ug + j) * 16) * 4u, hn[j]);
+          for (int j = 0; j < 4; ++j) bs1<HAUX>(hhh0, vrow, (unsigned)((16 * ug + j) * 16) * 4u, hn[j]);
         }
       }
     }
