@@ -1,6 +1,6 @@
 """A/B of the two forward decompositions against the fp64 oracle: worst element-wise error per tensor over
 several seeds, at the shape where one element of the clustered run crossed 1e-4 (scratch, uncollected)."""
-import sys; sys.path.insert(0, '/root/repo')
+import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tests import parity as P
 from paccmann_generator_amd import ops

@@ -1,6 +1,6 @@
 """Timing ablations (not collected by pytest): PMG_DEBUG bits skip phases of the kernels."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from paccmann_generator_amd import _ffi, ops

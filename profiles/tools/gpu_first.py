@@ -1,6 +1,6 @@
 """Bring-up script (not collected by pytest): run each parity check and print what it finds."""
 import sys, os, traceback
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tests import parity as P
 

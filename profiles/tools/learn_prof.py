@@ -1,6 +1,6 @@
 """Where learn()'s time goes beyond the three kernels (not collected by pytest)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from paccmann_generator_amd import ops

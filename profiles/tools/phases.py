@@ -1,6 +1,6 @@
 """Phase timings of one library variant (not collected by pytest).  PMG_LIB selects the .so."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 cfg = dict(bench.CONFIGS[os.environ.get('CFG', 'cfg2')])

@@ -1,9 +1,9 @@
 """In-kernel phase counters; not collected by pytest.  Needs a library built with -DPMG_PROFILE:
     python -c "import __graft_entry__ as g; g.build(extra_flags=['-DPMG_PROFILE'], libname='libpmg_prof.so')"
-    PMG_LIB=$PWD/paccmann_generator_amd/lib/libpmg_prof.so python tests/wip_prof.py
+    PMG_LIB=$PWD/paccmann_generator_amd/lib/libpmg_prof.so python profiles/tools/prof.py
 (PMG_DEBUG=0x8000 is set below.)"""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from paccmann_generator_amd import _ffi, ops

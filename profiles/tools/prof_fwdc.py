@@ -1,7 +1,7 @@
 """Phase counters of the clustered forward (uncollected).  Build: g.build(extra_flags=['-DPMG_PROFILE'], libname='libpmg_prof.so');
-run: PMG_LIB=.../libpmg_prof.so python tests/wip_prof_fwdc.py"""
+run: PMG_LIB=.../libpmg_prof.so python profiles/tools/prof_fwdc.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from paccmann_generator_amd import ops
