@@ -77,6 +77,42 @@ __device__ __forceinline__ float row16_sum(float x) {
   return x;
 }
 
+// Reductions over the 64 lanes of a wave on the DPP network: xor 1, xor 2 (quad permutes), mirror within 8 and within
+// 16 lanes, then row_bcast:15 / row_bcast:31 carry the row results up; lane 63 holds the result, read into a scalar.
+#define FC_DPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), ctrl, rmask, 0xf, false))
+#define FC_DPPI(x, ctrl, rmask) __builtin_amdgcn_update_dpp(x, x, ctrl, rmask, 0xf, false)
+// the builtin is typed int: a float argument would be CONVERTED, not moved
+__device__ __forceinline__ float readlane_f(const float x, const int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+__device__ __forceinline__ float wave_max(float x) {
+  x = fmaxf(x, FC_DPP(x, 0xB1, 0xf)); x = fmaxf(x, FC_DPP(x, 0x4E, 0xf));
+  x = fmaxf(x, FC_DPP(x, 0x141, 0xf)); x = fmaxf(x, FC_DPP(x, 0x140, 0xf));
+  x = fmaxf(x, FC_DPP(x, 0x142, 0xa)); x = fmaxf(x, FC_DPP(x, 0x143, 0xc));
+  return readlane_f(x, 63);
+}
+// sum in the order the network gives (log-softmax of the teacher-forced pass: tolerance, not bit pattern)
+__device__ __forceinline__ float wave_sum63(float x) {
+  x += FC_DPP(x, 0xB1, 0xf); x += FC_DPP(x, 0x4E, 0xf);
+  x += FC_DPP(x, 0x141, 0xf); x += FC_DPP(x, 0x140, 0xf);
+  const float r15 = FC_DPP(x, 0x142, 0xa);       // rows 1, 3: the row below's total (rows 0, 2: own value, dropped)
+  x = ((threadIdx.x & 16) ? x + r15 : x);
+  const float r31 = FC_DPP(x, 0x143, 0xc);       // rows 2, 3: total of rows 0-1
+  x = ((threadIdx.x & 32) ? x + r31 : x);
+  return readlane_f(x, 63);
+}
+// index of the largest value, the lowest index among equal values
+__device__ __forceinline__ int wave_argmax(float bv, int bi) {
+#define FC_AM(ctrl, rmask)                                                          \
+  {                                                                                 \
+    const float ov = FC_DPP(bv, ctrl, rmask); const int oi = FC_DPPI(bi, ctrl, rmask); \
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }                     \
+  }
+  FC_AM(0xB1, 0xf) FC_AM(0x4E, 0xf) FC_AM(0x141, 0xf) FC_AM(0x140, 0xf) FC_AM(0x142, 0xa) FC_AM(0x143, 0xc)
+#undef FC_AM
+  return __builtin_amdgcn_readlane(bi, 63);
+}
+
 // Cluster barrier in two halves, so that loads which do not depend on the exchange (the owners' extras
 // weights) can be issued between them and land while lane 0 polls.  arrive: every wave's sc1 stores
 // written through, workgroup barrier, lane 0 adds to the counter.  wait: lane 0 polls (bounded),
@@ -342,25 +378,23 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
       const float* xex = xexs + k * 256;
       const float* sold = stk + ((size_t)k * 2 + (i & 1)) * DW;
       float* snew = stk + ((size_t)k * 2 + ((i + 1) & 1)) * DW;
-      // ---- consume the logits of step i-1 (lanes 0..31: entry v sits in lane v & 31)
+      // ---- consume the logits of step i-1: the whole wave, entry v in lane v & 63; reductions on the DPP network
+      // (no LDS round trips), results read out of lane 63 into a scalar
       int tok = teacher ? ((rowok && i < N + 1) ? min(max((int)a.tok_in[(size_t)min(i, N) * B + row], 0), V - 1) : 0) : a.start_tok;
       int finflag = rowok ? 0 : 1;
-      if (i >= 1 && lane < 32) {
-        const int l5 = lane;
+      if (i >= 1) {
         const float* lg = xex + 3 + W;
         if (teacher) {
           float m = -INFINITY;
 #pragma unroll 1
-          for (int v = l5; v < V; v += 32) m = fmaxf(m, lg[v]);
-#pragma unroll
-          for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 32));
+          for (int v = lane; v < V; v += 64) m = fmaxf(m, lg[v]);
+          m = wave_max(m);
           float total = 0.0f;
 #pragma unroll 1
-          for (int v = l5; v < V; v += 32) total += __expf(lg[v] - m);
-#pragma unroll
-          for (int o = 16; o >= 1; o >>= 1) total += __shfl_xor(total, o, 32);
+          for (int v = lane; v < V; v += 64) total += __expf(lg[v] - m);
+          total = wave_sum63(total);
           const int y = tok;       // tokens[i][row]: the target of step i-1 and the input of step i
-          if ((y & 31) == l5) {
+          if ((y & 63) == lane) {
             const float lp = (lg[y] - m) - __logf(total);
             a.LP[((size_t)(i - 1) * G + g) * 16 + s] = lp;
             if (rowok) a.logp_out[(size_t)(i - 1) * B + row] = lp;
@@ -368,67 +402,63 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
           float* pr = a.PR + ((size_t)(i - 1) * G + g) * a.VP * 16;
           const float inv = __builtin_amdgcn_rcpf(total);
 #pragma unroll 2
-          for (int v = l5; v < V; v += 32) pr[ht ? s * a.VP + v : v * 16 + s] = __expf(lg[v] - m) * inv;
+          for (int v = lane; v < V; v += 64) pr[ht ? s * a.VP + v : v * 16 + s] = __expf(lg[v] - m) * inv;
         } else {
           bool fin = osi[k * 8 + 5] != 0;
           const bool greedy = !(a.temperature > 0.0f);
           if (greedy) {
             float bv = -INFINITY; int bi = 0x7fffffff;
-            for (int v = l5; v < V; v += 32) { const float x = lg[v]; if (x > bv) { bv = x; bi = v; } }
-#pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) {
-              const float ov = __shfl_xor(bv, o, 32); const int oi = __shfl_xor(bi, o, 32);
-              if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
-            tok = bi;
+            for (int v = lane; v < V; v += 64) { const float x = lg[v]; if (x > bv) { bv = x; bi = v; } }
+            tok = wave_argmax(bv, bi);            // largest value, lowest index among equals
           } else {
-            // same slot-wise inverse-CDF draw as pmg_fwd.hip (oracle twin: oracle/philox.py sample_row)
+            // same slot-wise inverse-CDF draw as pmg_fwd.hip (oracle twin: oracle/philox.py sample_row): 32-entry
+            // slots, Hillis-Steele scan inside a slot, running carry across slots.  Two slots ride in the two halves
+            // of the wave; every floating-point operation and its order are those of the one-slot-at-a-time form.
             const float T = a.temperature;
+            const int l5 = lane & 31, hs = lane >> 5;
             float m = -INFINITY;
-            for (int v = l5; v < V; v += 32) m = fmaxf(m, lg[v] / T);
-#pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 32));
+            for (int v = lane; v < V; v += 64) m = fmaxf(m, lg[v] / T);
+            m = wave_max(m);
             const float u = osm[k * 8 + 3];       // pmg_uniform(seed, global row, offset + i - 1), formed under barrier B
-            // running CDF: slot ks holds entries 32ks..32ks+31, one per lane (3+W+V <= 256 on this path)
-            float cdf[8];
+            float cdf[4];                          // pair p holds entries 64p..64p+63 (3+W+V <= 256 on this path)
             float carry = 0.0f;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-              cdf[ks] = 0.0f;
-              if (32 * ks < V) {
-                const int v = 32 * ks + l5;
+            for (int pr2 = 0; pr2 < 4; ++pr2) {
+              cdf[pr2] = 0.0f;
+              if (64 * pr2 < V) {
+                const int v = 64 * pr2 + lane;
                 float e = (v < V) ? __expf(lg[v] / T - m) : 0.0f;
 #pragma unroll
                 for (int o = 1; o <= 16; o <<= 1) {
                   const float t = __shfl_up(e, o, 32);
                   if (l5 >= o) e += t;
                 }
-                cdf[ks] = carry + e;
-                carry = __shfl(cdf[ks], 31, 32);
+                const float c0 = carry + readlane_f(e, 31);     // carry behind the even slot
+                cdf[pr2] = (hs == 0 ? carry : c0) + e;
+                // an odd slot past the end adds zeros: the carry stays what the even slot left, as when it is skipped
+                carry = (32 * (2 * pr2 + 1) < V) ? readlane_f(cdf[pr2], 63) : c0;
               }
             }
             const float target = u * carry;
             tok = -1;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-              if (32 * ks < V) {
-                const int v = 32 * ks + l5;
-                const unsigned mk = (unsigned)__ballot((v < V) && (target < cdf[ks]));
-                if (tok < 0 && mk) tok = 32 * ks + (__ffs(mk) - 1);
+            for (int pr2 = 0; pr2 < 4; ++pr2) {
+              if (64 * pr2 < V) {
+                const int v = 64 * pr2 + lane;
+                const unsigned long long mk = __ballot((v < V) && (target < cdf[pr2]));
+                if (tok < 0 && mk) tok = 64 * pr2 + (__ffsll((long long)mk) - 1);
               }
             }
             if (tok < 0) tok = V - 1;
           }
-          if (rowok && l5 == 0) a.tok_out[(size_t)row * N + (i - 1)] = tok;
+          if (rowok && lane == 0) a.tok_out[(size_t)row * N + (i - 1)] = tok;
           if (!fin && tok == a.stop_tok) {
             fin = true;
-            if (l5 == 0) { osi[k * 8 + 5] = 1; osi[k * 8 + 6] = i - 1; }
+            if (lane == 0) { osi[k * 8 + 5] = 1; osi[k * 8 + 6] = i - 1; }
           }
           if (fin) finflag = 1;
         }
       }
-      tok = __shfl(tok, 0);
-      finflag = __shfl(finflag, 0);
       FC_TICK(2)
       if (i < N) {
         // ---- stack controls; ROW 0 of the new stack (= the stack top the gates need) and the record
