@@ -75,14 +75,19 @@ __device__ __forceinline__ bool cluster_wait(unsigned* ctr, const unsigned targe
   return *okw != 0;
 }
 
-// sum over the 64 lanes of a wave (every lane gets the total)
+// sum over the 64 lanes of a wave on the DPP network (xor 1, xor 2, mirror within 8 and 16 lanes, row_bcast:15 / :31),
+// read out of lane 63 into a scalar: no LDS round trips
+#define BC_DPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), ctrl, rmask, 0xf, false))
 __device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
-  return x;
+  x += BC_DPP(x, 0xB1, 0xf); x += BC_DPP(x, 0x4E, 0xf);
+  x += BC_DPP(x, 0x141, 0xf); x += BC_DPP(x, 0x140, 0xf);
+  const float r15 = BC_DPP(x, 0x142, 0xa);       // rows 1, 3: the row below's total
+  x = ((threadIdx.x & 16) ? x + r15 : x);
+  const float r31 = BC_DPP(x, 0x143, 0xc);       // rows 2, 3: total of rows 0-1
+  x = ((threadIdx.x & 32) ? x + r31 : x);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));   // typed int: move, not convert
 }
 
-// LDS map (float offsets), shared by the kernel and the host-side size check.
 #define BC_HIST 336   // floats of forward history per owned sequence: PV[64] | push, pop, no-op, logp, token | .. | PR[V] from 72
 struct BcLds { unsigned wt_is, wt_x, red, own, dtls, r3s, dxls, hist, sprevs, dsb, misc, end; };
 __host__ __device__ inline BcLds bc_lds(const int NXT, const int NOWN, const int DW) {
