@@ -652,8 +652,9 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
       for (int j = 0; j < 4; ++j) hh[j * 16] = hn[j];
     }
     if (nown > 0) {
-      // under the wait: what the next step's owner phase needs and the exchange does not carry
-      load_chunk(0);
+      // under the wait: what the next step's owner phase needs and the exchange does not carry.  With a single chunk
+      // (hidden <= 256 and 3+W+V <= 128) the extras weights simply stay in their registers from step to step.
+      if (NCH > 1) load_chunk(0);
       if (decode && wave == 0 && lane < nown)
         osm[lane * 8 + 3] = pmg_uniform(a.seed, (uint64_t)(a.seq_base + row00 + cu + lane * C), a.offset + (uint64_t)i);
     }
