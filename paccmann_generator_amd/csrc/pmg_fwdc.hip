@@ -331,6 +331,34 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
   const int sd0 = tid / W, sw = (sd0 < SDS) ? tid - sd0 * W : W;
   const f32x4 bhn = (wave == 0) ? ld4(a.BG[0] + 3 * H + 16 * cu + 4 * q) : z4;
 
+  // hidden part of the gate pre-activations of this wave's K quarter: waves 0-3 r -> p0, z -> p1; waves 4-7 W_hn h -> p1
+  auto hidden_part = [&](const float4 (&x4)[HM], f32x4& p0, f32x4& p1) __attribute__((always_inline)) {
+    if (wave < 4) {
+#pragma unroll
+      for (int m = 0; m < HM; ++m) {
+        const float4 x = x4[m];
+        f32x4 wz;
+        if constexpr (ZREG) wz = wres[HM + m]; else wz = ld4(wlz + (size_t)(kq0 + m) * 256 + lane * 4);
+        p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][0], x.x, p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[0], x.x, p1, 0, 0, 0);
+        p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][1], x.y, p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[1], x.y, p1, 0, 0, 0);
+        p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][2], x.z, p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[2], x.z, p1, 0, 0, 0);
+        p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][3], x.w, p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[3], x.w, p1, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < HM; ++m) {
+        const float4 x = x4[m];
+        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][0], x.x, p1, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][1], x.y, p1, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][2], x.z, p1, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][3], x.w, p1, 0, 0, 0);
+      }
+    }
+  };
   FC_TICK(7)
   for (int i = 0; ok; ++i) {
     const __amdgpu_buffer_rsrc_t hin = (i & 1) ? hb1 : hb0, hout = (i & 1) ? hb0 : hb1;
@@ -486,7 +514,17 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
     FC_TICK(3)
     if (i == N) break;
     FC_ARRIVE();
-    // ---- deferred owner work, under the wait of barrier A: stack rows >= 1 and the teacher history
+    // ---- under the wait of barrier A.  The hidden part of the gates needs only h, which has been visible since
+    // barrier B: the blocks of group 0 are requested now, fly under the deferred owner work and are multiplied before
+    // the wait ends; the part that needs the records (stack tops, tokens) follows behind the barrier.
+    // (Up to hidden 256; at hidden 512 the product is longer than the wait and the early form measured slower.)
+    constexpr bool EARLY = HM <= 4;
+    float4 xs[HM];
+    if constexpr (EARLY) {
+#pragma unroll
+      for (int m = 0; m < HM; ++m) xs[m] = xld4(hin, (unsigned)((kq0 + m) * 256 + lane * 4) * 4u);
+    }
+    // ---- deferred owner work: stack rows >= 1 and the teacher history
     for (int k = 0; k < nown; ++k) {
       const int sg = cu + k * C;
       const int s = sg & 15, g = g0 + (sg >> 4);
@@ -520,43 +558,31 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
           a.TP[((size_t)i * G + g) * 2048 + (size_t)tid * 16 + s] = (rowok && osi[k * 8 + 4] == tid - 64) ? 1.0f : 0.0f;
       }
     }
+    f32x4 pa0 = z4, pa1 = z4;
+    if constexpr (EARLY) hidden_part(xs, pa0, pa1);
     if (!(ok = FC_WAIT())) break;                // A: tokens and stack tops of every sequence visible
 
     FC_TICK(4)
     // ================================================================ members: gates of the own 16 units, group by group
     int allfin = 1;                                          // wave 1, decode: every sequence so far has finished
-    // every exchanged operand of a wave is requested up front: one L2 round trip per group, not one per k group.
-    // (Requesting them a group ahead was measured slower: the registers it keeps live across the reduction
-    // and the cell spill, and the reloads cost more than the round trip -- profiles/r03_cluster_groups.md.)
-    float4 xt, xs[HM];
+    // (Requesting the operands of group r+1 a group ahead was measured slower: the registers it keeps live across the
+    // reduction and the cell spill, and the reloads cost more than the round trip -- profiles/r03_cluster_groups.md.)
+    float4 xt;
     float tkn = 0.0f;
     int fl = 1;
-    auto load_ops = [&](const int r) {
+    for (int r = 0; r < NGc; ++r) {
       xt = xld4(rec, (unsigned)((r * 16 + b) * 128 + 16 * kw + 4 * q) * 4u);                    // stack-top k group kw
-#pragma unroll
-      for (int m = 0; m < HM; ++m) xs[m] = xld4(hin, (unsigned)((r * KG + kq0 + m) * 256 + lane * 4) * 4u);
       if (wave == 0) tkn = xld1(rec, (unsigned)((r * 16 + b) * 128 + 64) * 4u);                 // token fed to row b at this step
       if (decode && wave == 1 && lane < 16) fl = __float_as_int(xld1(rec, (unsigned)((r * 16 + lane) * 128 + 65) * 4u));
-    };
-    for (int r = 0; r < NGc; ++r) {
-      load_ops(r);
       float* redr = red + (size_t)(r & 1) * 8 * 2 * 256;
-      f32x4 acc0 = z4, acc1 = z4;
-      if (wave < 4) {
+      f32x4 acc0 = pa0, acc1 = pa1;
+      if (!EARLY || r > 0) {
 #pragma unroll
-        for (int m = 0; m < HM; ++m) {
-          const float4 x = xs[m];
-          f32x4 wz;
-          if constexpr (ZREG) wz = wres[HM + m]; else wz = ld4(wlz + (size_t)(kq0 + m) * 256 + lane * 4);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][0], x.x, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[0], x.x, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][1], x.y, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[1], x.y, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][2], x.z, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[2], x.z, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][3], x.w, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[3], x.w, acc1, 0, 0, 0);
-        }
+        for (int m = 0; m < HM; ++m) xs[m] = xld4(hin, (unsigned)((r * KG + kq0 + m) * 256 + lane * 4) * 4u);
+        acc0 = z4; acc1 = z4;
+        hidden_part(xs, acc0, acc1);
+      }
+      if (wave < 4) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis0[0], xt.x, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis1[0], xt.x, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis0[1], xt.y, acc0, 0, 0, 0);
@@ -566,14 +592,6 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis0[3], xt.w, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis1[3], xt.w, acc1, 0, 0, 0);
       } else {
-#pragma unroll
-        for (int m = 0; m < HM; ++m) {            // acc1 = W_hn h
-          const float4 x = xs[m];
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][0], x.x, acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][1], x.y, acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][2], x.z, acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[m][3], x.w, acc1, 0, 0, 0);
-        }
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis0[0], xt.x, acc0, 0, 0, 0);   // acc0 = W_in[:, E:] top
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis0[1], xt.y, acc0, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wis0[2], xt.z, acc0, 0, 0, 0);
