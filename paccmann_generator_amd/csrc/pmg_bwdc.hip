@@ -221,8 +221,23 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
   // fetch in two halves: fetch_issue requests round m0 of a step's history into registers (8 stack elements per thread
   // ACROSS the owned sequences, and for two sequences the small items), fetch_commit puts them into LDS.
   float fv[8], f1[2], f2[2];
-  const int rpt = (D + SDS - 1) / SDS, MF = nown * rpt;      // stack elements per thread and step
-  auto fetch_issue = [&](const int p, const int m0, const int k0) __attribute__((always_inline)) {
+  // thread mapping of a fetch: t = index among the fetching threads, (sdx, swx) its stack row offset and column,
+  // SDSx rows apart, rptx rows per thread and sequence
+  struct FetchMap { int t, sdx, swx, SDSx, rptx; };
+  const int rpt = (D + SDS - 1) / SDS;
+  const FetchMap fm_all = {tid, sd0, sw, SDS, rpt};
+  // Helper fetch: with few row groups per cluster the waves that carry no group (wave >= NGc) have nothing to do between
+  // barrier B and barrier A (carry, cell backward).  They fetch the coming step's history there, so that its HBM latency
+  // leaves the wait of barrier A.  Needs at least four such waves, one round of eight stack elements per thread and room
+  // for the probabilities behind thread 128.
+  const int nhw = 8 - NGc, nth = 64 * nhw, hti = tid - 64 * NGc;
+  const int HSDS = nth / W > 0 ? nth / W : 1;
+  const int hsd0 = hti >= 0 ? hti / W : 0;
+  const FetchMap fm_help = {hti, hsd0, (hti >= 0 && hsd0 < HSDS) ? hti - hsd0 * W : W, HSDS, (D + HSDS - 1) / HSDS};
+  constexpr bool HFETCH = HM <= 4;               // (the registers it keeps fit up to hidden 256)
+  const bool hfetch = HFETCH && nhw >= 4 && nown * fm_help.rptx <= 8 && nown <= 2 && V + 128 <= nth && W <= nth;   // workgroup-uniform
+  auto fetch_issue = [&](const FetchMap& fm, const int p, const int m0, const int k0) __attribute__((always_inline)) {
+    const int tid = fm.t, sd0 = fm.sdx, sw = fm.swx, SDS = fm.SDSx, rpt = fm.rptx, MF = nown * fm.rptx;
     const bool virt = (p == N);
     // S_{p-1}: rows <= min(p-1, N-p, D-1) hold data (pmg_fwd.hip "live rows"), the rest is zero
     const int s_hi = (virt || p == 0) ? -1 : min(min(p - 1, N - p), D - 1);
@@ -256,7 +271,8 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
       }
     }
   };
-  auto fetch_commit = [&](const int p, const int m0, const int k0) __attribute__((always_inline)) {
+  auto fetch_commit = [&](const FetchMap& fm, const int p, const int m0, const int k0) __attribute__((always_inline)) {
+    const int tid = fm.t, sd0 = fm.sdx, sw = fm.swx, SDS = fm.SDSx, rpt = fm.rptx, MF = nown * fm.rptx;
     const bool virt = (p == N);
     if (!virt) {
 #pragma unroll
@@ -280,9 +296,9 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
   };
   // the whole history of a step, round by round (one memory latency per round)
   auto fetch_history = [&](const int p) __attribute__((always_inline)) {
-    for (int m0 = 0, k0 = 0; m0 < MF || k0 < nown; m0 += 8, k0 += 2) {
-      fetch_issue(p, m0, k0);
-      fetch_commit(p, m0, k0);
+    for (int m0 = 0, k0 = 0; m0 < nown * rpt || k0 < nown; m0 += 8, k0 += 2) {
+      fetch_issue(fm_all, p, m0, k0);
+      fetch_commit(fm_all, p, m0, k0);
     }
   };
   // saved gates and previous hidden state of the NEXT step's cell backward (wave r, own units of group r): requested
@@ -349,7 +365,7 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
           dg[((size_t)3 * H + j) * 16] = gg[j];
         }
       }
-      fetch_history(p);
+      if (!hfetch) fetch_history(p);
       if (mygrp && p >= 1) load_gates(p - 1);
       if (!(ok = BC_WAIT_RAW())) break;          // A: every member's dgate blocks and dtop partials visible
       BC_TICK(1)
@@ -489,6 +505,12 @@ __global__ __launch_bounds__(BC_THREADS, 2) void pmg_bwdc_kernel(const BwdArgs a
     BC_TICK(3)
     if (!(ok = BC_WAIT())) break;                // B: dx of every sequence visible
     BC_TICK(4)
+    if constexpr (HFETCH) {
+      if (hfetch && wave >= NGc && p >= 1) {       // helper waves: the coming step's history, off the chain
+        fetch_issue(fm_help, p - 1, 0, 0);
+        fetch_commit(fm_help, p - 1, 0, 0);
+      }
+    }
     // ================================================================ members: the new carry of the own units, one wave per group
     if (mygrp) {
       f32x4 acc0 = virt ? z4 : dhz + hhs, acc1 = z4;
