@@ -21,6 +21,7 @@ allocator makes that cheap), so calls on different streams or threads never shar
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -56,6 +57,44 @@ USE_CLUSTER = True
 
 def _cluster_flag() -> int:
     return 0 if USE_CLUSTER else _ffi.PMG_FLAG_NO_CLUSTER
+
+
+class _ClusterTurn:
+    """Clustered launches need every member of a cluster resident at once (include/pmg.h): two of them running
+    side by side on different streams of one device keep each other's members off the CUs and crawl (measured 100x
+    slower at 256 workgroups each, profiles/tools/concurrent_clusters.py) or, past a second, give up.  The operators
+    therefore take turns per device: a launch that may be clustered waits (on the device, not the host) for the
+    previous one issued through this module from ANOTHER stream, and leaves an event for the next.  Launches with
+    PMG_FLAG_NO_CLUSTER (ops.TrainSlice, USE_CLUSTER = False) do not take part."""
+    _lock = threading.Lock()
+    _last = {}          # device index -> (event, stream handle)
+
+    def __init__(self, device, flags: int):
+        self.idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        self.active = not (flags & _ffi.PMG_FLAG_NO_CLUSTER)
+
+    def __enter__(self):
+        if self.active:
+            self._lock.acquire()
+            stream = torch.cuda.current_stream(self.idx)
+            last = self._last.get(self.idx)
+            if last is not None and last[1] != stream.cuda_stream:
+                stream.wait_event(last[0])
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            try:
+                stream = torch.cuda.current_stream(self.idx)
+                last = self._last.get(self.idx)
+                # one event per device, recorded again after every launch: a wait captures the record current at
+                # the time of the wait_event call, so recording over it later does not disturb earlier waiters
+                ev = last[0] if last is not None else torch.cuda.Event()
+                ev.record(stream)
+                self._last[self.idx] = (ev, stream.cuda_stream)
+            finally:
+                self._lock.release()
+        return False
 
 
 def release_workspaces() -> None:
@@ -176,9 +215,10 @@ def _decode_op(latent: Tensor, params: Sequence[Tensor], w_l2h: Tensor, b_l2h: T
     lens = torch.empty(B, dtype=torch.int32, device=latent.device)
     wstruct, keep = _wstruct(params, d['L'], w_l2h, b_l2h)
     flags = (0 if early_exit else _ffi.PMG_FLAG_NO_EARLY_EXIT) | _cluster_flag()
-    rc = _ffi.lib.pmg_decode(C.byref(shape), C.byref(wstruct), _ffi._ptr(latent), int(start_tok), int(stop_tok),
-                             int(gen_len), float(temperature), int(seed), int(offset), int(seq_index_base),
-                             flags, _ffi._ptr(tokens), _ffi._ptr(lens), _ffi._ptr(ws), _ffi.current_stream())
+    with _ClusterTurn(latent.device, flags):
+        rc = _ffi.lib.pmg_decode(C.byref(shape), C.byref(wstruct), _ffi._ptr(latent), int(start_tok), int(stop_tok),
+                                 int(gen_len), float(temperature), int(seed), int(offset), int(seq_index_base),
+                                 flags, _ffi._ptr(tokens), _ffi._ptr(lens), _ffi._ptr(ws), _ffi.current_stream())
     _ffi.check(rc, 'pmg_decode')
     del keep
     return tokens, lens
@@ -257,9 +297,19 @@ def _check_train_inputs(tokens: Tensor, h0: Tensor, d: dict):
 
 
 def _fwd_call(shape, wstruct, tokens, h0, logp, ws, flags=0):
-    rc = _ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(tokens), _ffi._ptr(h0),
-                                   _ffi._ptr(logp), None, flags | _cluster_flag(), _ffi._ptr(ws), _ffi.current_stream())
+    flags = flags | _cluster_flag()
+    with _ClusterTurn(h0.device, flags):
+        rc = _ffi.lib.pmg_logprob_fwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(tokens), _ffi._ptr(h0),
+                                       _ffi._ptr(logp), None, flags, _ffi._ptr(ws), _ffi.current_stream())
     _ffi.check(rc, 'pmg_logprob_fwd')
+
+
+def _bwd_call(shape, wstruct, tokens, reward, scale, flags, gstruct, grad_h0, loss, ws):
+    with _ClusterTurn(grad_h0.device, flags):
+        rc = _ffi.lib.pmg_reinforce_bwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(tokens), _ffi._ptr(reward),
+                                        float(scale), flags, C.byref(gstruct), _ffi._ptr(grad_h0), _ffi._ptr(loss),
+                                        _ffi._ptr(ws), _ffi.current_stream())
+    _ffi.check(rc, 'pmg_reinforce_bwd')
 
 
 @torch.library.custom_op('pmg::logprob_fwd', mutates_args=())
@@ -310,10 +360,7 @@ def _reinforce_bwd_op(tokens: Tensor, reward: Tensor, scale: float, ws: Tensor, 
     gstruct, keep2 = _grad_struct(grads, d['L'])
     grad_h0 = torch.empty(d['L'], B, d['H'], dtype=torch.float32, device=tokens.device)
     loss = torch.empty(1, dtype=torch.float32, device=tokens.device)
-    rc = _ffi.lib.pmg_reinforce_bwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(tokens), _ffi._ptr(reward),
-                                    float(scale), _cluster_flag(), C.byref(gstruct), _ffi._ptr(grad_h0),
-                                    _ffi._ptr(loss), _ffi._ptr(ws), _ffi.current_stream())
-    _ffi.check(rc, 'pmg_reinforce_bwd')
+    _bwd_call(shape, wstruct, tokens, reward, scale, _cluster_flag(), gstruct, grad_h0, loss, ws)
     del keep, keep2
     return loss, grad_h0, grads
 
@@ -395,11 +442,8 @@ def _reinforce_loss_op(tokens: Tensor, h0: Tensor, reward: Tensor, scale: float,
         if with_grads:
             r_c = reward if whole else reward[lo:hi].contiguous()
             gh_c = grad_h0 if whole else torch.empty(L, hi - lo, H, dtype=torch.float32, device=dev)
-            rc = _ffi.lib.pmg_reinforce_bwd(C.byref(shape), C.byref(wstruct), _ffi._ptr(tok_c), _ffi._ptr(r_c),
-                                            float(scale),
-                                            (_ffi.PMG_FLAG_ACCUMULATE if i > 0 else 0) | _cluster_flag(),
-                                            C.byref(gstruct), _ffi._ptr(gh_c), _ffi._ptr(loss), _ffi._ptr(ws), st)
-            _ffi.check(rc, 'pmg_reinforce_bwd')
+            _bwd_call(shape, wstruct, tok_c, r_c, scale, (_ffi.PMG_FLAG_ACCUMULATE if i > 0 else 0) | _cluster_flag(),
+                      gstruct, gh_c, loss, ws)
             if not whole:
                 grad_h0[:, lo:hi] = gh_c
     if not with_grads:

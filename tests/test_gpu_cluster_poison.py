@@ -60,3 +60,48 @@ def test_cluster_that_cannot_assemble_gives_up_and_poisons(gpu):
     # and the device is fine afterwards
     tokens, lens = ops.decode(w, latent, 2, 3, T, temperature=0.0, seed=1)
     assert int(lens.min()) >= 0
+
+
+@pytest.mark.timeout(120)
+def test_clustered_launches_from_two_streams_take_turns(gpu):
+    """Two host threads, two streams, clustered launches of 256 workgroups each: left alone they keep each other's
+    cluster members off the CUs (100x slower, profiles/tools/concurrent_clusters.py before the guard).  The operators
+    make them take turns on the device (ops._ClusterTurn): same results as the serial runs, and about the serial time."""
+    import threading
+    from paccmann_generator_amd import ops
+    ops.USE_CLUSTER = True
+    cfg = dict(P.CFG1, rnn_cell_size=512)
+    _, pdec = P.make_pair(cfg, seed=0)
+    w = pdec.weights()
+    B, T, reps = 768, 30, 6
+    lat = [torch.randn(1, B, cfg['latent_dim'], device='cuda') for _ in range(2)]
+    ref = [ops.decode(w, l, 2, 3, T, temperature=0.9, seed=5 + i, early_exit=False) for i, l in enumerate(lat)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for i in range(2):
+            ops.decode(w, lat[i], 2, 3, T, temperature=0.9, seed=5 + i, early_exit=False)
+    torch.cuda.synchronize()
+    serial = time.perf_counter() - t0
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    out, errors = [None, None], []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                for _ in range(reps):
+                    out[i] = ops.decode(w, lat[i], 2, 3, T, temperature=0.9, seed=5 + i, early_exit=False)
+            streams[i].synchronize()
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    torch.cuda.synchronize()
+    both = time.perf_counter() - t0
+    assert not errors, errors
+    for i in range(2):
+        assert torch.equal(out[i][0], ref[i][0]) and torch.equal(out[i][1], ref[i][1])
+    assert both < 5.0 * serial + 0.05, (both, serial)
