@@ -190,7 +190,17 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
   const int NGc = (G - g0 < NG) ? G - g0 : NG;   // row groups of this cluster
   const int NS = 16 * NGc;                       // its sequences: sigma = 16 r + s, global row = 16 g0 + sigma
   const int NOWN = (16 * NG + C - 1) / C;        // owned sequences the LDS is laid out for
-  const int nown = (cu < NS) ? (NS - cu + C - 1) / C : 0;   // owned by this member: sigma = cu + k C
+  // Split ownership ("duo"): with one row group on a cluster of 32 members only 16 of them would own a sequence and each
+  // would stream the second half of the extras weights from L2 every step.  Instead member s keeps the control and push
+  // rows and does the stack side of sequence s, member s + 16 keeps the vocabulary rows and does its logits / sampling
+  // side: each half of the weights stays in registers for good, the two sides run in parallel, and they publish
+  // different lines of the sequence's record, so no exchange is added.
+  const bool duo = (C == 32) && NG == 1 && 3 + W <= 64 && V <= 64;
+  const int nown = duo ? 1 : (cu < NS) ? (NS - cu + C - 1) / C : 0;   // owned by this member: sigma = cu + k C
+  const int sgoff = duo ? (cu & 15) - cu : 0;                        // duo: sigma = cu mod 16
+  const bool roleA = !duo || cu < 16;              // stack side: controls, push value, stack update, its history
+  const bool roleB = !duo || cu >= 16;             // vocabulary side: logits -> log-prob / token, its history
+  const int rbase = (duo && !roleA) ? 3 + W : 0, rend = (duo && roleA) ? 3 + W : NX;   // extras rows of this member
   const int row00 = g0 * PMG_ROWS;
   const int DW = D * W;
 
@@ -274,18 +284,18 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
   // the two halves of barrier B, i.e. while the new hidden state is still on its way
   constexpr int RC = 16 / HM;                    // rows per register chunk (RC * HM <= 16 float4)
   const int l16 = tid & 15, rgrp = tid >> 4;
-  const int RX = (NX + 31) >> 5;                 // rows per 16-lane group
+  const int RX = (rend - rbase + 31) >> 5;       // rows per 16-lane group
   const int NCH = (RX + RC - 1) / RC;            // chunks (1 at hidden <= 256 and NX <= 128)
   f32x4 wreg[RC * HM];
   auto load_chunk = [&](const int c) {
 #pragma unroll
     for (int r = 0; r < RC; ++r) {
-      const int n = rgrp + 32 * (c * RC + r);
+      const int n = rbase + rgrp + 32 * (c * RC + r);
       const float* wr = (n < 3) ? a.w_ctrl + (size_t)n * H
                                 : (n < 3 + W) ? a.w_push + (size_t)(n - 3) * H : a.w_out + (size_t)(n - 3 - W) * H;
 #pragma unroll
       for (int m = 0; m < HM; ++m)
-        wreg[r * HM + m] = (n < NX) ? ld4(wr + 4 * l16 + 64 * m) : z4;
+        wreg[r * HM + m] = (n < rend) ? ld4(wr + 4 * l16 + 64 * m) : z4;
     }
   };
 
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
     // (1) hidden states of the owned sequences -> LDS (unit 16*kg + 4*kq + c sits in lane s + 16*kq of block kg)
     for (int t = tid; t < nown * (H / 4); t += FC_THREADS) {
       const int k = t / (H / 4), u4 = t - k * (H / 4);
-      const int sg = cu + k * C, r = sg >> 4, s = sg & 15;
+      const int sg = cu + k * C + sgoff, r = sg >> 4, s = sg & 15;
       const float4 v = xld4(hin, (unsigned)(((r * KG + (u4 >> 2)) * 64 + s + 16 * (u4 & 3)) * 4) * 4u);
       *reinterpret_cast<float4*>(hls + (size_t)k * H + 4 * u4) = v;
     }
@@ -381,7 +391,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
         for (int m = 0; m < HM; ++m) hv[m] = ld4(hls + (size_t)k * H + 4 * l16 + 64 * m);
 #pragma unroll
         for (int rr = 0; rr < RC; ++rr) {
-          const int n = rgrp + 32 * (c * RC + rr);
+          const int n = rbase + rgrp + 32 * (c * RC + rr);
           float acc = 0.0f;
 #pragma unroll
           for (int m = 0; m < HM; ++m) {
@@ -389,7 +399,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
             acc = fmaf(wreg[rr * HM + m][2], hv[m][2], acc); acc = fmaf(wreg[rr * HM + m][3], hv[m][3], acc);
           }
           acc = row16_sum(acc);
-          if (l16 == 0 && n < NX) xexs[k * 256 + n] = acc + bxl[n];
+          if (l16 == 0 && n < rend) xexs[k * 256 + n] = acc + bxl[n];
         }
       }
     }
@@ -398,7 +408,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
     // (3) one WAVE per owned sequence from here to the record: logits of step i-1 -> token, stack controls,
     // row 0 of the new stack, publish.  Nothing below needs a workgroup barrier.
     for (int k = wave; k < nown; k += 8) {
-      const int sg = cu + k * C;                  // wave-uniform: sequence of the cluster,
+      const int sg = cu + k * C + sgoff;          // wave-uniform: sequence of the cluster,
       const int r = sg >> 4, s = sg & 15;         // its row group and row,
       const int g = g0 + r;                       // the global row group
       const int row = row00 + sg;
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
       // (no LDS round trips), results read out of lane 63 into a scalar
       int tok = teacher ? ((rowok && i < N + 1) ? min(max((int)a.tok_in[(size_t)min(i, N) * B + row], 0), V - 1) : 0) : a.start_tok;
       int finflag = rowok ? 0 : 1;
-      if (i >= 1) {
+      if (i >= 1 && roleB) {
         const float* lg = xex + 3 + W;
         if (teacher) {
           float m = -INFINITY;
@@ -488,7 +498,11 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
         }
       }
       FC_TICK(2)
-      if (i < N) {
+      if (i < N && roleB) {
+        const float meta = (lane == 0) ? __int_as_float(tok) : (lane == 1) ? __int_as_float(finflag) : 0.0f;
+        xst1(rec, (unsigned)(sg * 128 + 64 + lane) * 4u, meta);
+      }
+      if (i < N && roleA) {
         // ---- stack controls; ROW 0 of the new stack (= the stack top the gates need) and the record
         // go out first: the rest of the update and every history store wait until this member has
         // arrived at barrier A (below), off the chain the other members wait on
@@ -505,8 +519,6 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
           snew[lane] = top;
         }
         xst1(rec, (unsigned)(sg * 128 + lane) * 4u, top);
-        const float meta = (lane == 0) ? __int_as_float(tok) : (lane == 1) ? __int_as_float(finflag) : 0.0f;
-        xst1(rec, (unsigned)(sg * 128 + 64 + lane) * 4u, meta);
         ptv[k * 128 + lane] = pv; ptv[k * 128 + 64 + lane] = top;
         if (lane == 0) { osm[k * 8] = apush; osm[k * 8 + 1] = apop; osm[k * 8 + 2] = anoop; osi[k * 8 + 4] = tok; }
       }
@@ -525,8 +537,8 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
       for (int m = 0; m < HM; ++m) xs[m] = xld4(hin, (unsigned)((kq0 + m) * 256 + lane * 4) * 4u);
     }
     // ---- deferred owner work: stack rows >= 1 and the teacher history
-    for (int k = 0; k < nown; ++k) {
-      const int sg = cu + k * C;
+    for (int k = 0; k < (roleA ? nown : 0); ++k) {
+      const int sg = cu + k * C + sgoff;
       const int s = sg & 15, g = g0 + (sg >> 4);
       const bool rowok = row00 + sg < B;
       const float* sold = stk + ((size_t)k * 2 + (i & 1)) * DW;
@@ -652,8 +664,8 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
     FC_ARRIVE();
     if (decode && misc[4]) {
       // every row of this cluster has emitted stop_tok: owners fill their rows' tails and all leave
-      for (int k = 0; k < nown; ++k) {
-        const int row = row00 + cu + k * C;
+      for (int k = 0; k < (roleB ? nown : 0); ++k) {
+        const int row = row00 + cu + k * C + sgoff;
         if (row < B)
           for (int t = i + tid; t < N; t += FC_THREADS) a.tok_out[(size_t)row * N + t] = a.stop_tok;
       }
@@ -673,8 +685,8 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
       // under the wait: what the next step's owner phase needs and the exchange does not carry.  With a single chunk
       // (hidden <= 256 and 3+W+V <= 128) the extras weights simply stay in their registers from step to step.
       if (NCH > 1) load_chunk(0);
-      if (decode && wave == 0 && lane < nown)
-        osm[lane * 8 + 3] = pmg_uniform(a.seed, (uint64_t)(a.seq_base + row00 + cu + lane * C), a.offset + (uint64_t)i);
+      if (decode && roleB && wave == 0 && lane < nown)
+        osm[lane * 8 + 3] = pmg_uniform(a.seed, (uint64_t)(a.seq_base + row00 + cu + lane * C + sgoff), a.offset + (uint64_t)i);
     }
     if (!(ok = FC_WAIT())) break;                // B: the new hidden state of every member visible
     FC_TICK(6)
@@ -689,7 +701,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
   if (!ok) {
     // gave up on a barrier: poison what the caller will look at
     for (int k = 0; k < nown; ++k) {
-      const int row = row00 + cu + k * C;
+      const int row = row00 + cu + k * C + sgoff;
       if (row < B) {
         if (decode && tid == 0) a.len_out[row] = -1;
         if (teacher) for (int t = tid; t < N; t += FC_THREADS) a.logp_out[(size_t)t * B + row] = __int_as_float(0x7fc00000);
@@ -699,8 +711,8 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
   }
   __syncthreads();
   if (decode && tid == 0)
-    for (int k = 0; k < nown; ++k) {
-      const int row = row00 + cu + k * C;
+    for (int k = 0; k < (roleB ? nown : 0); ++k) {
+      const int row = row00 + cu + k * C + sgoff;
       if (row < B) a.len_out[row] = osi[k * 8 + 6];
     }
   if (a.h_out != nullptr && wave == 0)
