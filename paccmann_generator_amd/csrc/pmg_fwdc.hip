@@ -189,15 +189,16 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
   if (g0 >= G) return;                           // a whole cluster absent: nobody waits for it
   const int NGc = (G - g0 < NG) ? G - g0 : NG;   // row groups of this cluster
   const int NS = 16 * NGc;                       // its sequences: sigma = 16 r + s, global row = 16 g0 + sigma
-  const int NOWN = (16 * NG + C - 1) / C;        // owned sequences the LDS is laid out for
+  const int NOWN = a.cluster_duo ? NG : (16 * NG + C - 1) / C;   // owned sequences the LDS is laid out for
   // Split ownership ("duo"): with one row group on a cluster of 32 members only 16 of them would own a sequence and each
   // would stream the second half of the extras weights from L2 every step.  Instead member s keeps the control and push
   // rows and does the stack side of sequence s, member s + 16 keeps the vocabulary rows and does its logits / sampling
   // side: each half of the weights stays in registers for good, the two sides run in parallel, and they publish
   // different lines of the sequence's record, so no exchange is added.
-  const bool duo = (C == 32) && NG == 1 && 3 + W <= 64 && V <= 64;
-  const int nown = duo ? 1 : (cu < NS) ? (NS - cu + C - 1) / C : 0;   // owned by this member: sigma = cu + k C
-  const int sgoff = duo ? (cu & 15) - cu : 0;                        // duo: sigma = cu mod 16
+  // With several row groups member s (s + 16) does its side for sequence s of every group: sigma = s + 16 k.
+  const bool duo = a.cluster_duo != 0;             // hidden 512, 3+W <= 64, V <= 64, NG stacks fit the LDS (host)
+  const int nown = duo ? NGc : (cu < NS) ? (NS - cu + C - 1) / C : 0;   // owned by this member: sigma = sq0 + k sqs
+  const int sq0 = duo ? (cu & 15) : cu, sqs = duo ? 16 : C;
   const bool roleA = !duo || cu < 16;              // stack side: controls, push value, stack update, its history
   const bool roleB = !duo || cu >= 16;             // vocabulary side: logits -> log-prob / token, its history
   const int rbase = (duo && !roleA) ? 3 + W : 0, rend = (duo && roleA) ? 3 + W : NX;   // extras rows of this member
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
     // (1) hidden states of the owned sequences -> LDS (unit 16*kg + 4*kq + c sits in lane s + 16*kq of block kg)
     for (int t = tid; t < nown * (H / 4); t += FC_THREADS) {
       const int k = t / (H / 4), u4 = t - k * (H / 4);
-      const int sg = cu + k * C + sgoff, r = sg >> 4, s = sg & 15;
+      const int sg = sq0 + k * sqs, r = sg >> 4, s = sg & 15;
       const float4 v = xld4(hin, (unsigned)(((r * KG + (u4 >> 2)) * 64 + s + 16 * (u4 & 3)) * 4) * 4u);
       *reinterpret_cast<float4*>(hls + (size_t)k * H + 4 * u4) = v;
     }
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
     // (3) one WAVE per owned sequence from here to the record: logits of step i-1 -> token, stack controls,
     // row 0 of the new stack, publish.  Nothing below needs a workgroup barrier.
     for (int k = wave; k < nown; k += 8) {
-      const int sg = cu + k * C + sgoff;          // wave-uniform: sequence of the cluster,
+      const int sg = sq0 + k * sqs;          // wave-uniform: sequence of the cluster,
       const int r = sg >> 4, s = sg & 15;         // its row group and row,
       const int g = g0 + r;                       // the global row group
       const int row = row00 + sg;
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
     }
     // ---- deferred owner work: stack rows >= 1 and the teacher history
     for (int k = 0; k < (roleA ? nown : 0); ++k) {
-      const int sg = cu + k * C + sgoff;
+      const int sg = sq0 + k * sqs;
       const int s = sg & 15, g = g0 + (sg >> 4);
       const bool rowok = row00 + sg < B;
       const float* sold = stk + ((size_t)k * 2 + (i & 1)) * DW;
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
     if (decode && misc[4]) {
       // every row of this cluster has emitted stop_tok: owners fill their rows' tails and all leave
       for (int k = 0; k < (roleB ? nown : 0); ++k) {
-        const int row = row00 + cu + k * C + sgoff;
+        const int row = row00 + sq0 + k * sqs;
         if (row < B)
           for (int t = i + tid; t < N; t += FC_THREADS) a.tok_out[(size_t)row * N + t] = a.stop_tok;
       }
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
       // (hidden <= 256 and 3+W+V <= 128) the extras weights simply stay in their registers from step to step.
       if (NCH > 1) load_chunk(0);
       if (decode && roleB && wave == 0 && lane < nown)
-        osm[lane * 8 + 3] = pmg_uniform(a.seed, (uint64_t)(a.seq_base + row00 + cu + lane * C + sgoff), a.offset + (uint64_t)i);
+        osm[lane * 8 + 3] = pmg_uniform(a.seed, (uint64_t)(a.seq_base + row00 + sq0 + lane * sqs), a.offset + (uint64_t)i);
     }
     if (!(ok = FC_WAIT())) break;                // B: the new hidden state of every member visible
     FC_TICK(6)
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
   if (!ok) {
     // gave up on a barrier: poison what the caller will look at
     for (int k = 0; k < nown; ++k) {
-      const int row = row00 + cu + k * C + sgoff;
+      const int row = row00 + sq0 + k * sqs;
       if (row < B) {
         if (decode && tid == 0) a.len_out[row] = -1;
         if (teacher) for (int t = tid; t < N; t += FC_THREADS) a.logp_out[(size_t)t * B + row] = __int_as_float(0x7fc00000);
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
   __syncthreads();
   if (decode && tid == 0)
     for (int k = 0; k < (roleB ? nown : 0); ++k) {
-      const int row = row00 + cu + k * C + sgoff;
+      const int row = row00 + sq0 + k * sqs;
       if (row < B) a.len_out[row] = osi[k * 8 + 6];
     }
   if (a.h_out != nullptr && wave == 0)
@@ -721,7 +722,13 @@ __global__ __launch_bounds__(FC_THREADS, 2) void pmg_fwdc_kernel(const FwdArgs a
 }
 
 // groups per cluster, owned sequences per member, LDS bytes without / with the token-table lines
-int fwdc_nown(const FwdArgs* a, int ng) { const int C = a->H / 16; return (16 * ng + C - 1) / C; }
+// split ownership (see the kernel): 32-member clusters whose control + push rows and vocabulary rows each fit one
+// register chunk, as long as a stack per row group fits the LDS of the stack-side members
+bool fwdc_duo(const FwdArgs* a, int ng) {
+  return a->H == 512 && 3 + a->W <= 64 && a->V <= 64 &&
+         (size_t)fc_lds(a->H, ng, ng, a->D * a->W).gtl * sizeof(float) <= (size_t)160 * 1024;
+}
+int fwdc_nown(const FwdArgs* a, int ng) { const int C = a->H / 16; return fwdc_duo(a, ng) ? ng : (16 * ng + C - 1) / C; }
 size_t fwdc_lds_base_bytes(const FwdArgs* a, int ng) {
   return (size_t)fc_lds(a->H, ng, fwdc_nown(a, ng), a->D * a->W).gtl * sizeof(float);
 }
@@ -758,6 +765,7 @@ hipError_t pmg_launch_fwdc(const FwdArgs* a0, hipStream_t st) {
   const int ng = pmg_cluster_ng(a0->G, a0->H), ncl = (a0->G + ng - 1) / ng;
   args.cluster_ng = ng;
   args.cluster_gtab_lds = fwdc_gtab_fits(a0, ng) ? 1 : 0;
+  args.cluster_duo = fwdc_duo(a0, ng) ? 1 : 0;
   args.cluster_hist_t = (a0->mode == PMG_FWD_TEACHER && a0->LAYW != nullptr &&
                          pmg_bwdc_shape_ok(a0->H, a0->L, a0->NX, a0->NXT, a0->V, a0->W, a0->D, a0->G)) ? 1 : 0;
   const FwdArgs* a = &args;

@@ -95,6 +95,7 @@ struct FwdArgs {
   float* CX; unsigned* CXS;
   int cluster_gtab_lds;    // set by pmg_launch_fwdc: the token-table lines of a member's units fit its LDS
   int cluster_ng;          // set by pmg_launch_fwdc: row groups per cluster
+  int cluster_duo;         // set by pmg_launch_fwdc: split ownership (stack side / vocabulary side), pmg_fwdc.hip
   int cluster_hist_t;      // set by pmg_launch_fwdc: stack / push / probability history per SEQUENCE (see LAYW)
   // History layout word (training workspaces of cluster-capable shapes, else NULL): 0 = the stack (SB), push
   // value (PV) and probability (PR) slabs interleave the 16 sequences of a row group innermost (what the
