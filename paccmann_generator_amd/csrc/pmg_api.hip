@@ -148,45 +148,46 @@ static bool misaligned16(const void* p) { return ((uintptr_t)p & 15u) != 0; }
 // Pack the forward operands (and, for training, the transposed ones).
 static int pack_weights(const PmgDims& d, const PmgLayout& lay, float* base, const pmg_weights* w, int mode,
                         bool with_l2h, hipStream_t st) {
+  PrepArgs prep;
+  memset(&prep, 0, sizeof(prep));
   PackArgs p;
   memset(&p, 0, sizeof(p));
   p.H = d.H; p.E = d.E; p.W = d.W; p.V = d.V; p.NX = d.NX; p.UPW = d.UPW; p.Z = d.Z;
   // extras
   p.kind = PK_WX; p.tiles = d.NXT; p.KG = d.KGH; p.src = w->w_ctrl; p.src2 = w->w_push; p.src3 = w->w_out;
   p.dst = base + lay.WXp;
-  HIPCHK(pmg_launch_pack(&p, st));
+  pmg_prep_add(&prep, &p);
   for (int l = 0; l < d.L; ++l) {
     p.kind = PK_WHH; p.tiles = 3 * d.UT; p.KG = d.KGH; p.src = w->w_hh[l]; p.dst = base + lay.WHHp[l];
-    HIPCHK(pmg_launch_pack(&p, st));
+    pmg_prep_add(&prep, &p);
     if (l == 0) { p.kind = PK_WIS; p.KG = PMG_KS / 16; } else { p.kind = PK_WIH; p.KG = d.KGH; }
     p.src = w->w_ih[l]; p.dst = base + lay.WIHp[l];
-    HIPCHK(pmg_launch_pack(&p, st));
+    pmg_prep_add(&prep, &p);
   }
   if (mode == PMG_MODE_DECODE) {
     if (with_l2h) {
     p.kind = PK_L2H; p.tiles = d.UT; p.KG = d.Z / 16; p.src = w->w_l2h; p.dst = base + lay.H0;
-    HIPCHK(pmg_launch_pack(&p, st));
+    pmg_prep_add(&prep, &p);
     }
   } else {
     p.kind = PK_WXT; p.tiles = d.UT; p.KG = d.NXT; p.src = w->w_ctrl; p.src2 = w->w_push; p.src3 = w->w_out;
     p.dst = base + lay.WXt;
-    HIPCHK(pmg_launch_pack(&p, st));
+    pmg_prep_add(&prep, &p);
     for (int l = 0; l < d.L; ++l) {
       p.kind = PK_WHHT; p.tiles = d.UT; p.KG = 3 * d.H / 16; p.src = w->w_hh[l]; p.dst = base + lay.WHHt[l];
-      HIPCHK(pmg_launch_pack(&p, st));
+      pmg_prep_add(&prep, &p);
       if (l == 0) { p.kind = PK_WIST; p.tiles = PMG_KS / 16; } else { p.kind = PK_WIHT; p.tiles = d.UT; }
       p.src = w->w_ih[l]; p.dst = base + lay.WIHt[l];
-      HIPCHK(pmg_launch_pack(&p, st));
+      pmg_prep_add(&prep, &p);
     }
   }
-  AuxArgs x;
-  memset(&x, 0, sizeof(x));
+  AuxArgs& x = prep.x;
   x.H = d.H; x.E = d.E; x.W = d.W; x.V = d.V; x.L = d.L; x.NX = d.NX; x.NXT = d.NXT;
   x.b_ctrl = w->b_ctrl; x.b_push = w->b_push; x.b_out = w->b_out;
   for (int l = 0; l < d.L; ++l) { x.b_ih[l] = w->b_ih[l]; x.b_hh[l] = w->b_hh[l]; x.BG[l] = base + lay.BG[l]; }
   x.emb = w->embedding; x.w_ih0 = w->w_ih[0];
   x.BX = base + lay.BX; x.GTAB = base + lay.GTAB;
-  HIPCHK(pmg_launch_aux(&x, st));
+  HIPCHK(pmg_launch_prep(&prep, st));
   return PMG_OK;
 }
 

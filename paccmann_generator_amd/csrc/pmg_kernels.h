@@ -49,8 +49,18 @@ struct AuxArgs {
   float* BX; float* BG[PMG_MAX_LAYERS]; float* GTAB;
 };
 
-hipError_t pmg_launch_pack(const PackArgs* a, hipStream_t st);
-hipError_t pmg_launch_aux(const AuxArgs* a, hipStream_t st);
+// One prepare launch per entry-point call: up to PMG_PREP_MAX packing jobs, the bias vectors and the token table;
+// job j owns blocks [first[j], first[j+1]) -- packing jobs first, then the biases, then the table.
+#define PMG_PREP_MAX (2 + 4 * PMG_MAX_LAYERS)
+struct PrepArgs {
+  int npack;
+  int first[PMG_PREP_MAX + 3];
+  PackArgs p[PMG_PREP_MAX];
+  AuxArgs x;
+};
+
+void pmg_prep_add(PrepArgs* a, const PackArgs* p);       // a zeroed PrepArgs, then one call per packing job
+hipError_t pmg_launch_prep(PrepArgs* a, hipStream_t st);  // a->x filled in by the caller
 
 // ------------------------------------------------------------------ forward
 #define PMG_FWD_DECODE 0

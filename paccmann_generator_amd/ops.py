@@ -380,8 +380,15 @@ def plan_chunks(d: dict, B: int, T: int, budget: Optional[int] = None, chunk: in
     whose training workspace fits ``budget`` bytes (default: workspace_budget(device), derived from
     the memory free on the device right now).  ``chunk`` > 0 fixes the slice size instead."""
     if chunk <= 0:
-        budget = workspace_budget(device) if budget is None else int(budget)
         need = lambda n: _ffi.workspace_bytes(_shape(d, n, T), _ffi.PMG_MODE_TRAIN)      # noqa: E731
+        if budget is None:
+            # the whole batch within what the driver alone reports free (a lower bound of the budget: no walk
+            # through the caching allocator's statistics, 0.1 ms of host time per call): one chunk
+            if torch.cuda.is_available() and torch.cuda.is_initialized() and \
+                    need(B) <= min(WORKSPACE_BUDGET_BYTES, WORKSPACE_FREE_FRACTION * torch.cuda.mem_get_info(device)[0]):
+                return [(0, B)]
+            budget = workspace_budget(device)
+        budget = int(budget)
         per16 = need(32) - need(16)
         fixed = need(16) - per16
         groups = max(1, int((budget - fixed) // max(1, per16)))

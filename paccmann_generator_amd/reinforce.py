@@ -649,14 +649,12 @@ def pad_rows_on_device(tokens: torch.Tensor, lens: torch.Tensor, stop_index: int
     """Device twin of reinforce.py:177-184 + pad_sequence (reinforce_omics.py:304): every row
     becomes tokens[:len] + [stop, stop], zero-padded, seq-major [T_max, B]."""
     B, N = tokens.shape
-    lens = lens.to(torch.int64)
+    L = lens.to(torch.int64).unsqueeze(0)
     if t_max is None:
-        t_max = int(lens.max().item()) + 2
+        t_max = int(L.max().item()) + 2 if B > 0 else 2
     pos = torch.arange(t_max, device=tokens.device).unsqueeze(1)  # [T,1]
-    body = torch.zeros(t_max, B, dtype=torch.int64, device=tokens.device)
-    n = min(N, t_max)
-    body[:n] = tokens.t()[:n]
-    L = lens.unsqueeze(0)
-    stop = torch.full_like(body, int(stop_index))
-    zero = torch.zeros_like(body)
-    return torch.where(pos < L, body, torch.where(pos < L + 2, stop, zero))
+    body = tokens.t()
+    # seven small launches where the obvious form (zeros + copy + full_like + zeros_like + two where) took fourteen:
+    # at a small batch each one is 5 us of a 2.6 ms step
+    body = body[:t_max] if t_max <= N else torch.nn.functional.pad(body, (0, 0, 0, t_max - N))
+    return torch.where(pos < L, body, torch.where(pos < L + 2, int(stop_index), 0))
