@@ -60,7 +60,9 @@ def test_train_parity_large_vocab(gpu):
     dict(vocab_size=5, embedding_size=5),                      # pad, unk, start, stop + one real token
     dict(vocab_size=189, stack_width=64),                      # 3 + W + V = 256: the extras tile limit
     dict(n_layers=4, rnn_cell_size=256, stack_depth=30),       # deepest GRU, stack deeper than the sequence
-], ids=['w64d2', 'w1e1', 'v5', 'v189w64', 'l4'])
+    dict(embedding_size=200, vocab_size=97),                   # token table: two embedding slices (128 + 72), two token blocks
+    dict(embedding_size=129, vocab_size=64),                   # a one-column second slice, exactly one token block
+], ids=['w64d2', 'w1e1', 'v5', 'v189w64', 'l4', 'e200v97', 'e129v64'])
 def test_parity_edge_shapes(gpu, over):
     cfg = dict(P.TINY, **over)
     P.check_train(cfg, B=19, T=7, tol=TOL)
