@@ -99,8 +99,10 @@ const char* pmg_strerror(int code);
 /* 0 if `s` is a shape the kernels support -- what StackGRUDecoder(params) of the reference's
  * drivers admits (examples/IC50/train_paccmann_rl.py:93-97) within: H a multiple of 128 in
  * [128,1024], 1<=W<=64, D>=2, 2<=V<=1024, 1<=L<=PMG_MAX_LAYERS, Z a multiple of 32 (decode), and the
- * per-workgroup state fitting the CU's 160 KiB of LDS (a very wide vocabulary together with many
- * layers may not) -- else the error code every entry point would return for it. */
+ * per-workgroup state fitting the CU's 160 KiB of LDS: the hidden state of every layer is kept there
+ * (L x 16 x H floats), so L x H up to about 2048 fits -- e.g. H = 1024: one layer with any V, two
+ * layers with 3 + W + V <= 400; H = 512: three layers with V <= 859, four with V <= 331 at W = 50
+ * (table in DESIGN.md section 6) -- else the error code every entry point would return for it. */
 int pmg_check_shape(const pmg_shape* s, int mode);
 
 /* Which launches would take the clustered small-batch kernels for shape `s` with these flags:

@@ -115,8 +115,12 @@ extern "C" int pmg_check_shape(const pmg_shape* s, int mode) {
   if (mode == PMG_MODE_TRAIN && s->T < 2) return PMG_E_SHAPE;
   if (mode == PMG_MODE_DECODE && (s->Z < 32 || s->Z % 32 != 0)) return PMG_E_SHAPE;
   const PmgDims d = pmg_dims(s);
+  // pmg_fwd.hip: hidden state of every layer + extras tiles; the decode's latent rows alias what is behind the hidden state
   size_t lds = ((size_t)d.L * 16 * d.HP + 16 * PMG_XTP + (size_t)16 * d.XP + 32) * 4;
-  if (mode == PMG_MODE_DECODE) lds += (size_t)16 * (d.Z + 8) * 4;
+  if (mode == PMG_MODE_DECODE) {
+    const size_t init = ((size_t)d.L * 16 * d.HP + (size_t)16 * (d.Z + 8)) * 4;
+    if (init > lds) lds = init;
+  }
   if (lds > 160 * 1024) return PMG_E_LDS;
   if (mode == PMG_MODE_TRAIN) {   // the BPTT needs at least one chunk buffer next to its extras tile
     BwdArgs b;

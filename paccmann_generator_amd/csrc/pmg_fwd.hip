@@ -402,8 +402,10 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
   float* xtop = h_lds + (size_t)L * 16 * HP;             // [16][PMG_XTP]
   float* xex = xtop + 16 * PMG_XTP;                      // [16][XP]
   int* misc = reinterpret_cast<int*>(xex + 16 * XP);     // [0..15] token, [16] all-done flag
-  float* lat = reinterpret_cast<float*>(misc + 32);      // decode only: [16][Z+8]
-  float* slds = lat + (MODE == PMG_FWD_DECODE ? 16 * (a.Z + 8) : 0);  // [KL][W*16] top rows of the stack
+  float* slds = reinterpret_cast<float*>(misc + 32);     // [KL][W*16] top rows of the stack
+  // decode only: the latent rows [16][Z+8] of the h0 product live where xtop .. slds will (nothing behind the
+  // hidden state is in use before the time loop; pmg_fwd_lds_bytes covers the larger of the two)
+  float* lat = xtop;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -420,10 +422,6 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
   const int dbg = PMG_DBG(a.dbg);
 
   // ---------------------------------------------------------------- init
-  for (int idx = tid; idx < 16 * PMG_XTP; idx += NTHR) xtop[idx] = 0.0f;
-  // LDS stack rows start at zero: the side job reads rows that hold no data yet without a mask
-  for (int idx = tid; idx < a.KL * W * 16; idx += NTHR) slds[idx] = 0.0f;
-  if (tid < 32) misc[tid] = 0;
   if (decode) {
     // h0 = latent_to_hidden(latent): same value for every layer (reinforce.py:160-170 path)
     const int ZP = a.Z + 8;
@@ -437,6 +435,7 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
       acc = gemm1(acc, wrs, voff, a.oL2H + (unsigned)t * (unsigned)(a.Z / 16) * 1024u, a.Z / 16, lat + b * ZP + 4 * q);
       for (int l = 0; l < L; ++l) st4(&h_lds[(size_t)(l * 16 + b) * HP + 16 * t + 4 * q], acc);
     }
+    __syncthreads();                 // the latent rows are dead: their LDS becomes xtop, xex, misc and the stack rows
   } else {
     for (int idx = tid; idx < L * 16 * H; idx += NTHR) {
       const int l = idx / (16 * H);
@@ -446,6 +445,10 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
       h_lds[(size_t)(l * 16 + bb) * HP + k] = v;
     }
   }
+  for (int idx = tid; idx < 16 * PMG_XTP; idx += NTHR) xtop[idx] = 0.0f;
+  // LDS stack rows start at zero: the side job reads rows that hold no data yet without a mask
+  for (int idx = tid; idx < a.KL * W * 16; idx += NTHR) slds[idx] = 0.0f;
+  if (tid >= 16 && tid < 32) misc[tid] = 0;
   if (tid < 16) {
     int t0 = a.start_tok;
     // ids outside [0,V) are clamped (memory safety only: callers validate, ops.reinforce_loss does)
@@ -917,9 +920,11 @@ __global__ __launch_bounds__(WV * 64, WV / 4) void pmg_fwd_kernel(const FwdArgs 
 }  // namespace
 
 static size_t fwd_lds_base_bytes(const FwdArgs* a) {
-  size_t fl = (size_t)a->L * 16 * a->HP + 16 * PMG_XTP + (size_t)16 * a->XP + 32;
-  if (a->mode == PMG_FWD_DECODE) fl += (size_t)16 * (a->Z + 8);
-  return fl * sizeof(float);
+  return ((size_t)a->L * 16 * a->HP + 16 * PMG_XTP + (size_t)16 * a->XP + 32) * sizeof(float);
+}
+// decode: hidden state + the latent rows of the h0 product, which alias everything behind the hidden state
+static size_t fwd_lds_init_bytes(const FwdArgs* a) {
+  return a->mode == PMG_FWD_DECODE ? ((size_t)a->L * 16 * a->HP + (size_t)16 * (a->Z + 8)) * sizeof(float) : 0;
 }
 
 // PMG_FWD_LDS_STACK=0 keeps the whole stack in the global slab (A/B knob)
@@ -938,7 +943,10 @@ int pmg_fwd_stack_rows(const FwdArgs* a) {
   return (int)(k < (size_t)a->D ? k : (size_t)a->D);
 }
 
-size_t pmg_fwd_lds_bytes(const FwdArgs* a) { return fwd_lds_base_bytes(a) + (size_t)a->KL * a->W * 64; }
+size_t pmg_fwd_lds_bytes(const FwdArgs* a) {
+  const size_t loop = fwd_lds_base_bytes(a) + (size_t)a->KL * a->W * 64, init = fwd_lds_init_bytes(a);
+  return loop > init ? loop : init;
+}
 
 template <int WV, int UPW, int TPP, int MODE, bool MULTI>
 static hipError_t launch_fwd_t(const FwdArgs* a, hipStream_t st) {
