@@ -142,7 +142,10 @@ def main():
             latent2 = learner.encode_cell_line('a', B)
             smiles, nums, valid = learner.get_smiles_from_latent(latent2)
             (padded, _), bd['padded_valid'] = tm(lambda: learner._padded_valid(nums, valid))
-            _, bd['learn'] = tm(lambda: learner.learn(latent2, padded, valid, np.full(len(nums), 0.5, np.float32), 2))
+            # median of three: the first call after the calls above may pay for a fresh workspace allocation
+            # (a fresh encoder graph per call: learn() backpropagates through it)
+            bd['learn'] = sorted(tm(lambda lat=learner.encode_cell_line('a', B): learner.learn(
+                lat, padded, valid, np.full(len(nums), 0.5, np.float32), 2))[1] for _ in range(3))[1]
             out['breakdown_ms'] = bd
     pipelined(B, out, pools)
     for p in pools:
