@@ -3,10 +3,10 @@ clustered kernels have their own sweep, tests/test_gpu_cluster_fuzz.py): every h
 to four layers, stack widths and depths from the narrowest to the reference's 50 x 50 and the widest, vocabularies on
 both sides of every tile boundary of the extras product (64, 253, several column tiles), embedding sizes on both sides
 of the token table's 128-column slices, ragged batches, sequence lengths down to two steps.  Same bars as the parity
-modules.  `python -m tests.test_gpu_shape_fuzz SEED N` runs a longer sweep by hand (seeds 0..4 x 40 when written: 32
-shapes refused for LDS, 163 within every bar, 5 tiny shapes -- one to three sequences, two steps or a two-row stack --
-with one small gradient entry at 1.2e-4 .. 2.5e-4 of the element-wise bar while the max-norm bar holds; listed in
-profiles/r03_parity_seed_sweep.txt)."""
+modules.  `python -m tests.test_gpu_shape_fuzz SEED N` runs a longer sweep by hand (seeds 0..7 x 40 when written: 47
+shapes refused for LDS, 261 within every bar, 12 with ONE small gradient entry at 1.0e-4 .. 2.5e-4 of the element-wise
+bar -- deep or wide models, or a handful of sequences / steps -- while the max-norm bar, loss and log-probs hold in all;
+listed and discussed in profiles/r03_parity_seed_sweep.txt)."""
 import ctypes as C
 import random
 import sys
