@@ -306,7 +306,9 @@ def main():
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
 
-    if args.no_cluster:
+    if args.no_cluster or world > max(1, torch.cuda.device_count()):
+        # ranks that share a GPU (the gloo rehearsal on a box with fewer GPUs than ranks) must not both launch clustered
+        # kernels: every member of a cluster has to be resident at once (include/pmg.h, PMG_FLAG_NO_CLUSTER)
         from paccmann_generator_amd import ops as _ops
         _ops.USE_CLUSTER = False
     cfg = dict(CONFIGS[args.config])
